@@ -1,0 +1,262 @@
+"""die-e_amd -- host-side mirror (Python/ctypes) of the reference interface for the self-play hot
+path, over the C ABI in include/diee.h (libdiee.so: hand-written HIP for gfx950).
+
+The method names follow the reference's own API for this path so parity tests read like the
+reference's tests:
+
+    LearnableGame trait (src/base.rs:8-51)        -> Engine.get_valid_moves / encode / decode /
+                                                     apply_move / as_tensor        (batched)
+    ResNet::forward_t (src/alphazero/nnet.rs:120) -> Engine.forward_t
+    alpha_mcts_parallel + get_prob_tensor_parallel (src/mcts/alpha_mcts.rs:91, utils.rs:42)
+                                                  -> Engine.alpha_mcts_parallel
+    AlphaZero::self_play_parallel (src/alphazero/alpha_parallel.rs:101) -> Engine.self_play_parallel
+
+There is no CPU fallback: the library must load and a GPU must be present, otherwise the
+constructor raises.  Import with importlib.import_module("die-e_amd") (the directory name is
+not a Python identifier) or through the `diee_amd` shim at the repo root.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiee.so")
+
+BG_ACTIONS = 1352
+BG_PLANES = 144
+NO_MOVE = -2
+GAME_TTT, GAME_BACKGAMMON = 0, 1
+FLAG_REF_QUIRKS = 1
+
+OK, ERR_ARG, ERR_HIP, ERR_NO_WEIGHTS, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
+
+BG_STATE = np.dtype([("pts", "i1", 24), ("bar", "u1", 2), ("off", "u1", 2), ("roll", "u1", 2),
+                     ("player", "i1"), ("second", "u1")])
+assert BG_STATE.itemsize == 32
+
+# every symbol include/diee.h declares (checked by the CPU test-suite against the built library)
+EXPORTS = [
+    "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
+    "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
+    "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
+    "diee_bg_planes", "diee_probe_f32", "diee_probe_dice",
+]
+
+
+class DieeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"diee status {status}: {msg}")
+        self.status = status
+
+
+class MctsConfig(C.Structure):
+    """MctsConfig, src/lib.rs:33-40"""
+    _fields_ = [("iterations", C.c_uint32), ("c", C.c_float), ("round_limit", C.c_uint32),
+                ("dir_alpha", C.c_float), ("dir_eps", C.c_float)]
+
+    @classmethod
+    def default(cls, iterations=100):
+        # config-example.toml:11-15
+        return cls(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("games", "plies", "move_steps", "nn_evals", "expansions", "children",
+                                           "terminal_hits", "depth_sum", "selections", "illegal_decodes",
+                                           "max_children", "fragments")]
+                + [("seconds", C.c_double), ("nn_seconds", C.c_double), ("conv_seconds", C.c_double),
+                   ("conv_launches", C.c_uint64), ("conv_flops", C.c_double)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Fragments(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("outcome", C.POINTER(C.c_int8)), ("ps", C.POINTER(C.c_float)),
+                ("state", C.POINTER(C.c_float)), ("game", C.POINTER(C.c_uint32))]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libdiee.so and declare the prototypes.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(f"{p} is missing: build it with `python die-e_amd/build.py` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(p)
+    vp, u32, u64, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
+    L.diee_version.restype = C.c_char_p
+    L.diee_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]; L.diee_create.restype = C.c_int
+    L.diee_destroy.argtypes = [vp]; L.diee_destroy.restype = None
+    L.diee_last_error.argtypes = [vp]; L.diee_last_error.restype = C.c_char_p
+    L.diee_weights_count.argtypes = [C.c_int]; L.diee_weights_count.restype = C.c_size_t
+    L.diee_random_weights.argtypes = [C.c_int, u64, vp, C.c_size_t]; L.diee_random_weights.restype = C.c_int
+    L.diee_load_weights.argtypes = [vp, vp, C.c_size_t]; L.diee_load_weights.restype = C.c_int
+    L.diee_nn_forward.argtypes = [vp, vp, u32, vp, vp]; L.diee_nn_forward.restype = C.c_int
+    L.diee_mcts_batch.argtypes = [vp, vp, u32, vp, u64, u32, vp, vp, u32, vp, vp, vp, vp]
+    L.diee_mcts_batch.restype = C.c_int
+    L.diee_self_play.argtypes = [vp, u32, u32, vp, f32, u64, u32, u32, vp, vp]; L.diee_self_play.restype = C.c_int
+    L.diee_free_fragments.argtypes = [vp]; L.diee_free_fragments.restype = None
+    L.diee_bg_legal_moves.argtypes = [vp, vp, u32, vp, u32, vp]; L.diee_bg_legal_moves.restype = C.c_int
+    L.diee_bg_encode.argtypes = [vp, vp, vp, u32, vp]; L.diee_bg_encode.restype = C.c_int
+    L.diee_bg_decode.argtypes = [vp, vp, vp, u32, vp]; L.diee_bg_decode.restype = C.c_int
+    L.diee_bg_apply.argtypes = [vp, vp, vp, vp, u32]; L.diee_bg_apply.restype = C.c_int
+    L.diee_bg_planes.argtypes = [vp, vp, u32, vp]; L.diee_bg_planes.restype = C.c_int
+    L.diee_probe_f32.argtypes = [vp, vp, vp, u32, vp, vp, vp]; L.diee_probe_f32.restype = C.c_int
+    L.diee_probe_dice.argtypes = [vp, u64, vp, u32, vp, vp]; L.diee_probe_dice.restype = C.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+def weights_count(game_id=GAME_BACKGAMMON):
+    return int(load_library().diee_weights_count(game_id))
+
+
+def random_weights(seed=0, game_id=GAME_BACKGAMMON):
+    """tch-default random init of the ResNet (nnet.rs:57-107) as the flat fp32 blob of include/diee.h"""
+    L = load_library()
+    n = int(L.diee_weights_count(game_id))
+    blob = np.zeros(n, dtype=np.float32)
+    st = L.diee_random_weights(game_id, seed, blob.ctypes.data, n)
+    if st != OK:
+        raise DieeError(st, "diee_random_weights")
+    return blob
+
+
+def _states(a):
+    a = np.ascontiguousarray(a)
+    assert a.dtype.itemsize == 32 or (a.dtype == np.uint8 and a.shape[-1] == 32), a.dtype
+    return a
+
+
+class Engine:
+    """one engine per GPU (diee_ctx)"""
+
+    def __init__(self, device=0, game_id=GAME_BACKGAMMON):
+        self._L = load_library()
+        h = C.c_void_p()
+        st = self._L.diee_create(device, game_id, C.byref(h))
+        if st != OK:
+            raise DieeError(st, "diee_create failed (no HIP device / unsupported game): the HIP path is the only path")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.diee_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st != OK:
+            raise DieeError(st, self._L.diee_last_error(self._h).decode())
+
+    # ---- LearnableGame trait, batched -------------------------------------------------------
+    def get_valid_moves(self, states, cap=256):
+        """get_valid_moves (backgammon_logic.rs:403-414) -> (plays int8 [n,cap,4], counts uint32 [n])"""
+        s = _states(states); n = len(s)
+        plays = np.full((n, cap, 4), NO_MOVE, dtype=np.int8)
+        counts = np.zeros(n, dtype=np.uint32)
+        self._chk(self._L.diee_bg_legal_moves(self._h, s.ctypes.data, n, plays.ctypes.data, cap, counts.ctypes.data))
+        # slots past the count are unspecified on the device side: blank them
+        idx = np.arange(cap)[None, :] >= counts[:, None]
+        plays[idx] = NO_MOVE
+        return plays, counts
+
+    def encode(self, states, plays):
+        s = _states(states); p = np.ascontiguousarray(plays, dtype=np.int8); n = len(s)
+        assert p.shape == (n, 4)
+        codes = np.zeros(n, dtype=np.uint32)
+        self._chk(self._L.diee_bg_encode(self._h, s.ctypes.data, p.ctypes.data, n, codes.ctypes.data))
+        return codes
+
+    def decode(self, states, codes):
+        s = _states(states); c = np.ascontiguousarray(codes, dtype=np.uint32); n = len(s)
+        plays = np.zeros((n, 4), dtype=np.int8)
+        self._chk(self._L.diee_bg_decode(self._h, s.ctypes.data, c.ctypes.data, n, plays.ctypes.data))
+        return plays
+
+    def apply_move(self, states, plays, dice):
+        s = _states(states).copy(); p = np.ascontiguousarray(plays, dtype=np.int8)
+        d = np.ascontiguousarray(dice, dtype=np.uint8); n = len(s)
+        assert p.shape == (n, 4) and d.shape == (n, 2)
+        self._chk(self._L.diee_bg_apply(self._h, s.ctypes.data, p.ctypes.data, d.ctypes.data, n))
+        return s
+
+    def as_tensor(self, states):
+        s = _states(states); n = len(s)
+        out = np.zeros((n, BG_PLANES), dtype=np.float32)
+        self._chk(self._L.diee_bg_planes(self._h, s.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def probe_f32(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+        sq, dv, pw = (np.zeros_like(a) for _ in range(3))
+        self._chk(self._L.diee_probe_f32(self._h, a.ctypes.data, b.ctypes.data, len(a), sq.ctypes.data,
+                                         dv.ctypes.data, pw.ctypes.data))
+        return sq, dv, pw
+
+    def probe_dice(self, seed, ctr):
+        ctr = np.ascontiguousarray(ctr, dtype=np.uint32); n = len(ctr)
+        dice = np.zeros((n, 2), dtype=np.uint8); uni = np.zeros(n, dtype=np.float64)
+        self._chk(self._L.diee_probe_dice(self._h, seed, ctr.ctypes.data, n, dice.ctypes.data, uni.ctypes.data))
+        return dice, uni
+
+    # ---- ResNet ------------------------------------------------------------------------------
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._chk(self._L.diee_load_weights(self._h, blob.ctypes.data, blob.size))
+
+    def forward_t(self, states):
+        """ResNet::forward_t (nnet.rs:120-133), eval mode -> (softmax policy [n,1352], tanh value [n])"""
+        s = _states(states); n = len(s)
+        pol = np.zeros((n, BG_ACTIONS), dtype=np.float32); val = np.zeros(n, dtype=np.float32)
+        self._chk(self._L.diee_nn_forward(self._h, s.ctypes.data, n, pol.ctypes.data, val.ctypes.data))
+        return pol, val
+
+    # ---- search ------------------------------------------------------------------------------
+    def alpha_mcts_parallel(self, states, cfg, seed=0, step=0, game_ids=None, rounds=None, ref_quirks=True):
+        """alpha_mcts_parallel + get_prob_tensor_parallel -> dict(probs [n,1352], n_children, root_visits, stats)"""
+        s = _states(states); n = len(s)
+        probs = np.zeros((n, BG_ACTIONS), dtype=np.float32)
+        nch = np.zeros(n, dtype=np.uint32); rv = np.zeros(n, dtype=np.float32)
+        gi = None if game_ids is None else np.ascontiguousarray(game_ids, dtype=np.uint32)
+        rd = None if rounds is None else np.ascontiguousarray(rounds, dtype=np.uint32)
+        st = Stats()
+        self._chk(self._L.diee_mcts_batch(self._h, s.ctypes.data, n, C.byref(cfg), seed, step,
+                                          None if gi is None else gi.ctypes.data,
+                                          None if rd is None else rd.ctypes.data,
+                                          FLAG_REF_QUIRKS if ref_quirks else 0,
+                                          probs.ctypes.data, nch.ctypes.data, rv.ctypes.data, C.byref(st)))
+        return {"probs": probs, "n_children": nch, "root_visits": rv, "stats": st.as_dict()}
+
+    def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0xD1EE0001, ref_quirks=True,
+                           first_game_id=0, max_steps=0, fetch=True):
+        """AlphaZero::self_play_parallel -> dict(outcome, ps, state, game, stats)"""
+        fr = Fragments(); st = Stats()
+        self._chk(self._L.diee_self_play(self._h, n_games, first_game_id, C.byref(cfg), temperature, seed,
+                                         FLAG_REF_QUIRKS if ref_quirks else 0, max_steps,
+                                         C.byref(fr) if fetch else None, C.byref(st)))
+        out = {"stats": st.as_dict()}
+        if fetch:
+            n = fr.n
+            out["outcome"] = np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8)
+            out["ps"] = (np.ctypeslib.as_array(fr.ps, shape=(n, BG_ACTIONS)).copy() if n
+                         else np.zeros((0, BG_ACTIONS), np.float32))
+            out["state"] = (np.ctypeslib.as_array(fr.state, shape=(n, BG_PLANES)).copy() if n
+                            else np.zeros((0, BG_PLANES), np.float32))
+            out["game"] = np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            self._L.diee_free_fragments(C.byref(fr))
+        return out

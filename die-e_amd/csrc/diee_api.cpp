@@ -1,0 +1,164 @@
+// diee_api.cpp -- C ABI (include/diee.h) and host-side engine of libdiee.so.
+#include "../../include/diee.h"
+#include "engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <new>
+
+using namespace diee;
+
+#define API_BEGIN(ctx)            \
+    if (!(ctx)) return DIEE_ERR_ARG; \
+    (ctx)->err[0] = 0;            \
+    try {
+#define API_END(ctx)                                                        \
+    }                                                                       \
+    catch (const EngineError& e) {                                          \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s", e.what());           \
+        return (diee_status)e.code;                                         \
+    }                                                                       \
+    catch (const std::bad_alloc&) {                                         \
+        snprintf((ctx)->err, sizeof((ctx)->err), "host allocation failed"); \
+        return DIEE_ERR_HIP;                                                \
+    }                                                                       \
+    return DIEE_OK;
+
+struct diee_ctx : public Engine {
+    using Engine::Engine;
+};
+
+extern "C" {
+
+const char* diee_version(void) { return "die-e_amd 0.1 (gfx950)"; }
+
+diee_status diee_create(int device, int game_id, diee_ctx** out) {
+    if (!out) return DIEE_ERR_ARG;
+    *out = nullptr;
+    if (game_id != DIEE_GAME_BACKGAMMON) return DIEE_ERR_UNSUPPORTED;   // ttt is oracle-only
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DIEE_ERR_HIP;
+    diee_ctx* c = nullptr;
+    try {
+        c = new diee_ctx(device);
+    } catch (...) {
+        delete c;
+        return DIEE_ERR_HIP;
+    }
+    *out = c;
+    return DIEE_OK;
+}
+
+void diee_destroy(diee_ctx* c) { delete c; }
+
+const char* diee_last_error(const diee_ctx* c) { return c ? c->err : "null ctx"; }
+
+diee_status diee_bg_legal_moves(diee_ctx* c, const diee_bg_state* s, uint32_t n, int8_t* plays, uint32_t cap,
+                                uint32_t* counts) {
+    API_BEGIN(c)
+    if (!s || !plays || !counts) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->legal_moves(s, n, plays, cap, counts);
+    API_END(c)
+}
+
+diee_status diee_bg_encode(diee_ctx* c, const diee_bg_state* s, const int8_t* plays, uint32_t n, uint32_t* codes) {
+    API_BEGIN(c)
+    if (!s || !plays || !codes) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->encode(s, plays, n, codes);
+    API_END(c)
+}
+
+diee_status diee_bg_decode(diee_ctx* c, const diee_bg_state* s, const uint32_t* codes, uint32_t n, int8_t* plays) {
+    API_BEGIN(c)
+    if (!s || !plays || !codes) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->decode(s, codes, n, plays);
+    API_END(c)
+}
+
+diee_status diee_bg_apply(diee_ctx* c, diee_bg_state* s, const int8_t* plays, const uint8_t* dice, uint32_t n) {
+    API_BEGIN(c)
+    if (!s || !plays || !dice) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->apply(s, plays, dice, n);
+    API_END(c)
+}
+
+diee_status diee_bg_planes(diee_ctx* c, const diee_bg_state* s, uint32_t n, float* out) {
+    API_BEGIN(c)
+    if (!s || !out) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->planes(s, n, out);
+    API_END(c)
+}
+
+diee_status diee_probe_f32(diee_ctx* c, const float* a, const float* b, uint32_t n, float* sq, float* dv, float* pw) {
+    API_BEGIN(c)
+    c->probe_f32(a, b, n, sq, dv, pw);
+    API_END(c)
+}
+
+diee_status diee_probe_dice(diee_ctx* c, uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni) {
+    API_BEGIN(c)
+    c->probe_dice(seed, ctr, n, dice, uni);
+    API_END(c)
+}
+
+}  // extern "C"
+
+// ---- network / search entry points ---------------------------------------------------------------
+namespace diee {
+size_t weights_count_bg();
+void random_weights_bg(uint64_t seed, float* blob);
+}
+
+extern "C" {
+
+size_t diee_weights_count(int game_id) { return game_id == DIEE_GAME_BACKGAMMON ? diee::weights_count_bg() : 0; }
+
+diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t n) {
+    if (game_id != DIEE_GAME_BACKGAMMON) return DIEE_ERR_UNSUPPORTED;
+    if (!blob || n != diee::weights_count_bg()) return DIEE_ERR_ARG;
+    diee::random_weights_bg(seed, blob);
+    return DIEE_OK;
+}
+
+diee_status diee_load_weights(diee_ctx* c, const float* blob, size_t n) {
+    API_BEGIN(c)
+    if (!blob) throw EngineError(DIEE_ERR_ARG, "null blob");
+    c->load_weights(blob, n);
+    API_END(c)
+}
+
+diee_status diee_nn_forward(diee_ctx* c, const diee_bg_state* states, uint32_t n, float* policy, float* value) {
+    API_BEGIN(c)
+    if (!states || !policy || !value) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->nn_forward_host(states, n, policy, value);
+    API_END(c)
+}
+
+diee_status diee_mcts_batch(diee_ctx* c, const diee_bg_state* roots, uint32_t n, const diee_mcts_cfg* cfg,
+                            uint64_t seed, uint32_t step, const uint32_t* game_ids, const uint32_t* rounds,
+                            uint32_t flags, float* visit_probs, uint32_t* n_children, float* root_visits,
+                            diee_stats* stats) {
+    API_BEGIN(c)
+    if (!roots || !cfg || !visit_probs) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->mcts_batch(roots, n, cfg, seed, step, game_ids, rounds, flags, visit_probs, n_children, root_visits, stats);
+    API_END(c)
+}
+
+diee_status diee_self_play(diee_ctx* c, uint32_t n_games, uint32_t first_game_id, const diee_mcts_cfg* cfg,
+                           float temperature, uint64_t seed, uint32_t flags, uint32_t max_steps,
+                           diee_fragments* out, diee_stats* stats) {
+    API_BEGIN(c)
+    if (!cfg || n_games == 0) throw EngineError(DIEE_ERR_ARG, "bad arguments");
+    c->self_play(n_games, first_game_id, cfg, temperature, seed, flags, max_steps, out, stats);
+    API_END(c)
+}
+
+void diee_free_fragments(diee_fragments* f) {
+    if (!f) return;
+    free(f->outcome); free(f->ps); free(f->state); free(f->game);
+    memset(f, 0, sizeof *f);
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// engine.h -- host-side engine behind the C ABI: owns the HIP stream, HBM buffers and drives the
+// kernels.  No CPU compute path exists: every method launches HIP kernels on `device`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/diee.h"
+
+namespace diee {
+
+struct EngineError : public std::runtime_error {
+    int code;
+    EngineError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw ::diee::EngineError(DIEE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIPCHK(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+    }
+    size_t bytes() const { return cap * sizeof(T); }
+};
+
+struct NetWeights;   // nn_host.cpp
+struct SearchBufs;   // search_host.cpp
+
+class Engine {
+public:
+    char err[512];
+    explicit Engine(int device);
+    ~Engine();
+
+    // pure game functions
+    void legal_moves(const diee_bg_state* s, uint32_t n, int8_t* plays, uint32_t cap, uint32_t* counts);
+    void encode(const diee_bg_state* s, const int8_t* plays, uint32_t n, uint32_t* codes);
+    void decode(const diee_bg_state* s, const uint32_t* codes, uint32_t n, int8_t* plays);
+    void apply(diee_bg_state* s, const int8_t* plays, const uint8_t* dice, uint32_t n);
+    void planes(const diee_bg_state* s, uint32_t n, float* out);
+    void probe_f32(const float* a, const float* b, uint32_t n, float* sq, float* dv, float* pw);
+    void probe_dice(uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni);
+
+    // network
+    void load_weights(const float* blob, size_t n);
+    void nn_forward_host(const diee_bg_state* states, uint32_t n, float* policy, float* value);
+
+    // search / self-play
+    void mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_cfg* cfg, uint64_t seed, uint32_t step,
+                    const uint32_t* game_ids, const uint32_t* rounds, uint32_t flags, float* visit_probs,
+                    uint32_t* n_children, float* root_visits, diee_stats* stats);
+    void self_play(uint32_t n_games, uint32_t first_game_id, const diee_mcts_cfg* cfg, float temperature,
+                   uint64_t seed, uint32_t flags, uint32_t max_steps, diee_fragments* out, diee_stats* stats);
+
+    int device;
+    hipStream_t stream = nullptr;
+
+    template <class T>
+    void h2d(T* dst, const T* src, size_t n) {
+        if (n) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, stream));
+    }
+    template <class T>
+    void d2h(T* dst, const T* src, size_t n) {
+        if (n) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    }
+    void sync() { HIPCHK(hipStreamSynchronize(stream)); }
+    void check_overflow();
+
+    DevBuf<uint8_t> tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
+    DevBuf<uint32_t> flags_dev;      // [0] capacity-overflow flag
+    NetWeights* net = nullptr;
+    SearchBufs* search = nullptr;
+};
+
+}  // namespace diee

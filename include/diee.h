@@ -1,0 +1,172 @@
+/*
+ * diee.h -- C ABI of the MI355X-native die-e self-play engine (libdiee.so, gfx950 / CDNA4).
+ *
+ * Drop-in boundary for ONE hot path of alibasaran/die-e: batched AlphaZero-style self-play for
+ * backgammon (step dynamics + MCTS + policy/value ResNet).  The reference has no FFI of its own;
+ * the seam is the Rust generic function pair
+ *
+ *     alpha_mcts_parallel(&mut NodeStore<T>, &[T], &ResNet, &MctsConfig, Option<ProgressBar>)
+ *                                                             src/mcts/alpha_mcts.rs:91
+ *     get_prob_tensor_parallel(&[&Node<T>], &NodeStore<T>) -> Tensor[N,1352]
+ *                                                             src/mcts/utils.rs:42
+ *
+ * called from AlphaZero::self_play_parallel (src/alphazero/alpha_parallel.rs:101-231, at :146-166)
+ * and get_actions_for_player (src/versus.rs:279-283).  Each entry point below names the reference
+ * interface it replaces.  INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes; all pointers are HOST pointers unless a name ends in
+ * `_dev`; the caller owns inputs and pre-sized outputs; the engine owns `diee_fragments` until
+ * diee_free_fragments.  Errors are status codes (the reference panics); diee_last_error() gives
+ * text.  One diee_ctx per GPU; calls on a ctx must be serialised by the caller; contexts are
+ * independent (that is the multi-GPU story: one process per GPU, games block-partitioned).
+ * Every compute entry point runs hand-written HIP kernels on the ctx's device; there is no CPU
+ * fallback -- without a GPU diee_create fails with DIEE_ERR_HIP.
+ */
+#ifndef DIEE_H
+#define DIEE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIEE_BG_ACTIONS 1352u   /* Backgammon::ACTION_SPACE_SIZE, backgammon_logic.rs:74 */
+#define DIEE_BG_PLANES  144u    /* 6 x 4 x 6,  backgammon_logic.rs:75-76,198-252         */
+#define DIEE_NO_MOVE    (-2)    /* filler for the unused (from,to) slots of a play         */
+#define DIEE_GAME_TTT        0  /* tic-tac-toe: oracle/CPU plumbing only, no HIP kernels   */
+#define DIEE_GAME_BACKGAMMON 1
+
+typedef enum {
+    DIEE_OK = 0,
+    DIEE_ERR_ARG = 1,          /* bad argument                                            */
+    DIEE_ERR_HIP = 2,          /* HIP runtime error / no device                           */
+    DIEE_ERR_NO_WEIGHTS = 3,   /* diee_load_weights has not been called                   */
+    DIEE_ERR_CAPACITY = 4,     /* tree arena / sequence buffer overflow (never silent)    */
+    DIEE_ERR_UNSUPPORTED = 5
+} diee_status;
+
+/* Backgammon{board,roll,player,is_second_play}, backgammon_logic.rs:10,53-60 (id dropped: it is
+ * only a HashMap key in the arena, versus.rs:178,220).  32 bytes. */
+typedef struct {
+    int8_t  pts[24];           /* Board.0: <0 player -1 ("Player 1"), >0 player +1        */
+    uint8_t bar[2];            /* Board.1: (p-1, p+1) checkers on the bar                 */
+    uint8_t off[2];            /* Board.2: (p-1, p+1) checkers collected                  */
+    uint8_t roll[2];           /* as rolled                                               */
+    int8_t  player;
+    uint8_t second;            /* is_second_play                                          */
+} diee_bg_state;
+
+/* MctsConfig, src/lib.rs:33-40 (keys: iterations, exploration_const, simulate_round_limit,
+ * dirichlet_alpha, dirichlet_epsilon; config-example.toml:11-15) */
+typedef struct {
+    uint32_t iterations;
+    float    c;
+    uint32_t round_limit;
+    float    dir_alpha, dir_eps;
+} diee_mcts_cfg;
+
+/* flags */
+#define DIEE_FLAG_REF_QUIRKS 1u /* reproduce SURVEY Appendix A Q14 (stale selected_nodes_idxs
+                                   slots, alpha_mcts.rs:142,157-166,175-200) and Q18 (double
+                                   flush, alpha_parallel.rs:172-180,215-223)                */
+
+typedef struct {
+    uint64_t games;            /* games retired (winner or round limit)                    */
+    uint64_t plies;            /* rounds played, skipped turns included                    */
+    uint64_t move_steps;       /* passes of the while loop, alpha_parallel.rs:129          */
+    uint64_t nn_evals;         /* batch rows pushed through the ResNet (stale rows too)    */
+    uint64_t expansions;       /* first-time node expansions, roots included               */
+    uint64_t children;         /* nodes created below roots                                */
+    uint64_t terminal_hits;    /* selections ending on a terminal leaf                     */
+    uint64_t depth_sum;        /* sum of leaf depths over selections                       */
+    uint64_t selections;
+    uint64_t illegal_decodes;  /* alpha_parallel.rs:204 self-check failures (counted)      */
+    uint64_t max_children;
+    uint64_t fragments;
+    double   seconds;          /* wall clock of the call, inputs resident                  */
+    double   nn_seconds;       /* HIP-event time of the ResNet kernels                     */
+    double   conv_seconds;     /* HIP-event time of the 3x3 tower conv kernel alone        */
+    uint64_t conv_launches;    /* launches of that kernel                                  */
+    double   conv_flops;       /* algorithmic FLOPs those launches performed               */
+} diee_stats;
+
+/* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */
+typedef struct {
+    uint32_t  n;
+    int8_t*   outcome;         /* [n]        +1 / -1 / 0                                   */
+    float*    ps;              /* [n][1352]  (visits/sum)^(1/T), not renormalised (Q17)    */
+    float*    state;           /* [n][144]   as_tensor planes, c*24 + point                */
+    uint32_t* game;            /* [n]        originating game id (extra)                   */
+} diee_fragments;
+
+typedef struct diee_ctx diee_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+diee_status diee_create(int device, int game_id, diee_ctx** out);
+void        diee_destroy(diee_ctx*);
+const char* diee_last_error(const diee_ctx*);      /* valid until the next call on the ctx */
+const char* diee_version(void);
+
+/* ---- network weights ---------------------------------------------------------------------
+ * Replaces ResNet::new / VarStore::load (src/alphazero/nnet.rs:57-118, alphazero.rs:81-100).
+ * The blob is fp32 in the creation order of nnet.rs:62-97:
+ *   init:   conv.w[256][6][3][3] conv.b[256]  bn.gamma bn.beta bn.mean bn.var [256 each]
+ *   19 x:   conv1.w[256][256][3][3] conv1.b  conv2.w conv2.b  bn1.{g,b,m,v}  bn2.{g,b,m,v}
+ *   policy: conv.w[32][256][3][3] conv.b[32] bn.{g,b,m,v}[32] fc.w[1352][768] fc.b[1352]
+ *   value:  conv.w[3][256][3][3]  conv.b[3]  bn.{g,b,m,v}[3]  fc.w[1][72]     fc.b[1]
+ * BatchNorm is folded (eval mode, eps 1e-5) and weights are packed to bf16 MFMA fragments. */
+size_t      diee_weights_count(int game_id);
+/* tch-default random init (nnet.rs: kaiming-uniform conv/linear weights, conv bias 0, linear bias
+ * U(+-1/sqrt(fan_in)), BN gamma U(0,1), beta 0, mean 0, var 1) from a counter-based generator */
+diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t n);
+diee_status diee_load_weights(diee_ctx*, const float* blob, size_t n);
+
+/* ---- ResNet::forward_t, nnet.rs:120-133 (eval mode): softmax policy [n][1352], tanh value [n] */
+diee_status diee_nn_forward(diee_ctx*, const diee_bg_state* states, uint32_t n,
+                            float* policy, float* value);
+
+/* ---- level 1: alpha_mcts_parallel (alpha_mcts.rs:91) + get_prob_tensor_parallel (utils.rs:42)
+ * roots[i] must have dice rolled.  game_ids/rounds (may be NULL: i / 0) key the child dice.
+ * visit_probs[n][1352]: root child visits / row sum (rows of roots without children are NaN,
+ * like the reference's 0/0); n_children[n]; child_visits (optional, [n][cap] in child order). */
+diee_status diee_mcts_batch(diee_ctx*, const diee_bg_state* roots, uint32_t n,
+                            const diee_mcts_cfg* cfg, uint64_t seed, uint32_t step,
+                            const uint32_t* game_ids, const uint32_t* rounds, uint32_t flags,
+                            float* visit_probs, uint32_t* n_children,
+                            float* root_visits /* [n] or NULL */, diee_stats* stats);
+
+/* ---- level 2: AlphaZero::self_play_parallel, alpha_parallel.rs:101-231
+ * n_games = num_self_play_batches; first_game_id offsets the RNG keys (rank * n_games when games
+ * are sharded over GPUs); max_steps = 0 plays to completion. */
+diee_status diee_self_play(diee_ctx*, uint32_t n_games, uint32_t first_game_id,
+                           const diee_mcts_cfg* cfg, float temperature, uint64_t seed,
+                           uint32_t flags, uint32_t max_steps,
+                           diee_fragments* out /* may be NULL: keep results in HBM only */,
+                           diee_stats* stats);
+void        diee_free_fragments(diee_fragments*);
+
+/* ---- pure game functions, batched on the GPU (parity tests; LearnableGame trait, base.rs:8-51)
+ * A play is int8 {f1,t1,f2,t2}; unused slots DIEE_NO_MOVE. */
+/* get_valid_moves, backgammon_logic.rs:403-414: plays[n][cap][4], counts[n] (count may exceed cap) */
+diee_status diee_bg_legal_moves(diee_ctx*, const diee_bg_state* s, uint32_t n,
+                                int8_t* plays, uint32_t cap, uint32_t* counts);
+/* encode / decode, backgammon_logic.rs:262-359 / :361-401 */
+diee_status diee_bg_encode(diee_ctx*, const diee_bg_state* s, const int8_t* plays /*[n][4]*/,
+                           uint32_t n, uint32_t* codes);
+diee_status diee_bg_decode(diee_ctx*, const diee_bg_state* s, const uint32_t* codes, uint32_t n,
+                           int8_t* plays /*[n][4]*/);
+/* apply_move, backgammon_logic.rs:176-186, with the dice roll_die would draw (dice[n][2]) */
+diee_status diee_bg_apply(diee_ctx*, diee_bg_state* s /* in/out */, const int8_t* plays,
+                          const uint8_t* dice, uint32_t n);
+/* as_tensor, backgammon_logic.rs:198-252: out[n][144] */
+diee_status diee_bg_planes(diee_ctx*, const diee_bg_state* s, uint32_t n, float* out);
+/* device arithmetic probes for the bit-exactness tests (f32 sqrt/div, det_pow, Philox dice) */
+diee_status diee_probe_f32(diee_ctx*, const float* a, const float* b, uint32_t n,
+                           float* sqrt_a, float* a_div_b, float* pow_ab);
+diee_status diee_probe_dice(diee_ctx*, uint64_t seed, const uint32_t* ctr /*[n][4]*/, uint32_t n,
+                            uint8_t* dice /*[n][2]*/, double* uniform /*[n]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

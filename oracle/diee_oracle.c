@@ -916,3 +916,54 @@ void or_hash_eval(void* ctx, const or_state* states, int n, float* policy, float
     }
     free(pl);
 }
+
+/* ======================================================================== */
+/* Batch helpers for the parity tests (test infrastructure)                  */
+/* ======================================================================== */
+
+/* states reached by seeded uniformly-random legal play from Backgammon::new() */
+int or_random_walk_states(uint64_t seed, uint32_t n_games, uint32_t max_plies, or_bg_state* out, int cap) {
+    int n = 0;
+    or_play* plays = malloc(sizeof(or_play) * OR_MAX_PLAYS);
+    for (uint32_t g = 0; g < n_games && n < cap; ++g) {
+        or_bg_state s; or_bg_new(&s);
+        uint8_t d0, d1; or_dice(seed, g, 0, OR_TAG_INIT_ROLL, 0, &d0, &d1);
+        s.roll[0] = d0; s.roll[1] = d1;
+        for (uint32_t ply = 0; ply < max_plies && n < cap; ++ply) {
+            int w;
+            if (or_bg_check_winner(&s, &w)) break;
+            out[n++] = s;
+            int k = or_bg_valid_moves(&s, plays, OR_MAX_PLAYS);
+            or_dice(seed, g, ply, OR_TAG_MOVE_ROLL, 0, &d0, &d1);
+            if (k == 0) { or_bg_skip_turn(&s, d0, d1); continue; }
+            double u = or_uniform01(seed, g, ply, OR_TAG_SAMPLE, 0);
+            int j = (int)(u * k); if (j >= k) j = k - 1;
+            or_bg_apply_move(&s, &plays[j], d0, d1);
+        }
+    }
+    free(plays);
+    return n;
+}
+
+/* plays[n][cap] (4 bytes each), counts[n] */
+void or_bg_valid_moves_batch(const or_bg_state* s, int n, int8_t* plays, int cap, uint32_t* counts) {
+    or_play* tmp = malloc(sizeof(or_play) * OR_MAX_PLAYS);
+    for (int i = 0; i < n; ++i) {
+        int k = or_bg_valid_moves(&s[i], tmp, OR_MAX_PLAYS);
+        counts[i] = (uint32_t)k;
+        for (int j = 0; j < k && j < cap; ++j) memcpy(plays + ((size_t)i * cap + j) * 4, tmp[j].mv, 4);
+    }
+    free(tmp);
+}
+void or_bg_encode_batch(const or_bg_state* s, const int8_t* plays, int n, uint32_t* codes) {
+    for (int i = 0; i < n; ++i) { or_play p; memcpy(p.mv, plays + (size_t)i * 4, 4); codes[i] = or_bg_encode(&s[i], &p); }
+}
+void or_bg_decode_batch(const or_bg_state* s, const uint32_t* codes, int n, int8_t* plays) {
+    for (int i = 0; i < n; ++i) { or_play p; or_bg_decode(&s[i], codes[i], &p); memcpy(plays + (size_t)i * 4, p.mv, 4); }
+}
+void or_bg_apply_batch(or_bg_state* s, const int8_t* plays, const uint8_t* dice, int n) {
+    for (int i = 0; i < n; ++i) { or_play p; memcpy(p.mv, plays + (size_t)i * 4, 4); or_bg_apply_move(&s[i], &p, dice[2 * i], dice[2 * i + 1]); }
+}
+void or_bg_planes_batch(const or_bg_state* s, int n, float* out) {
+    for (int i = 0; i < n; ++i) or_bg_planes(&s[i], out + (size_t)i * OR_BG_PLANES);
+}

@@ -182,6 +182,14 @@ void or_free_fragments(or_fragments* f);
 /* a cheap deterministic evaluator for CPU-only tests (NOT a network) */
 void or_hash_eval(void* ctx /* const or_game* */, const or_state* states, int n, float* policy, float* value);
 
+/* batch helpers for the parity tests */
+int  or_random_walk_states(uint64_t seed, uint32_t n_games, uint32_t max_plies, or_bg_state* out, int cap);
+void or_bg_valid_moves_batch(const or_bg_state* s, int n, int8_t* plays, int cap, uint32_t* counts);
+void or_bg_encode_batch(const or_bg_state* s, const int8_t* plays, int n, uint32_t* codes);
+void or_bg_decode_batch(const or_bg_state* s, const uint32_t* codes, int n, int8_t* plays);
+void or_bg_apply_batch(or_bg_state* s, const int8_t* plays, const uint8_t* dice, int n);
+void or_bg_planes_batch(const or_bg_state* s, int n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

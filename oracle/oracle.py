@@ -110,6 +110,12 @@ def lib():
         L.or_self_play_parallel.argtypes = [vp, u32, u32, vp, C.c_float, u64, EVAL_FN, vp, i, u32, vp, vp, vp, vp]
         L.or_self_play_parallel.restype = i
         L.or_free_fragments.argtypes = [vp]
+        L.or_random_walk_states.argtypes = [u64, u32, u32, vp, i]; L.or_random_walk_states.restype = i
+        L.or_bg_valid_moves_batch.argtypes = [vp, i, vp, i, vp]
+        L.or_bg_encode_batch.argtypes = [vp, vp, i, vp]
+        L.or_bg_decode_batch.argtypes = [vp, vp, i, vp]
+        L.or_bg_apply_batch.argtypes = [vp, vp, vp, i]
+        L.or_bg_planes_batch.argtypes = [vp, i, vp]
         _lib = L
     return _lib
 
@@ -346,4 +352,49 @@ def self_play_parallel(game_id, n_games, cfg, temperature, seed, eval_fn, ectx, 
         "steps": steps, "plies": plies, "winners": winners, "stats": stats.as_dict(),
     }
     L.or_free_fragments(C.byref(fr))
+    return out
+
+
+# --------------------------------------------------------------------------- batch helpers
+def random_walk_states(seed, n_games, max_plies=400, cap=None):
+    cap = cap or n_games * max_plies
+    out = np.zeros(cap, dtype=BG_STATE)
+    n = lib().or_random_walk_states(seed, n_games, max_plies, out.ctypes.data, cap)
+    return out[:n].copy()
+
+
+def valid_moves_batch(states, cap=256):
+    states = np.ascontiguousarray(states)
+    n = len(states)
+    plays = np.full((n, cap, 4), NO_MOVE, dtype=np.int8)
+    counts = np.zeros(n, dtype=np.uint32)
+    lib().or_bg_valid_moves_batch(states.ctypes.data, n, plays.ctypes.data, cap, counts.ctypes.data)
+    return plays, counts
+
+
+def encode_batch(states, plays):
+    states = np.ascontiguousarray(states); plays = np.ascontiguousarray(plays, dtype=np.int8)
+    codes = np.zeros(len(states), dtype=np.uint32)
+    lib().or_bg_encode_batch(states.ctypes.data, plays.ctypes.data, len(states), codes.ctypes.data)
+    return codes
+
+
+def decode_batch(states, codes):
+    states = np.ascontiguousarray(states); codes = np.ascontiguousarray(codes, dtype=np.uint32)
+    plays = np.zeros((len(states), 4), dtype=np.int8)
+    lib().or_bg_decode_batch(states.ctypes.data, codes.ctypes.data, len(states), plays.ctypes.data)
+    return plays
+
+
+def apply_batch(states, plays, dice):
+    out = np.ascontiguousarray(states).copy(); plays = np.ascontiguousarray(plays, dtype=np.int8)
+    dice = np.ascontiguousarray(dice, dtype=np.uint8)
+    lib().or_bg_apply_batch(out.ctypes.data, plays.ctypes.data, dice.ctypes.data, len(out))
+    return out
+
+
+def planes_batch(states):
+    states = np.ascontiguousarray(states)
+    out = np.zeros((len(states), BG_PLANES), dtype=np.float32)
+    lib().or_bg_planes_batch(states.ctypes.data, len(states), out.ctypes.data)
     return out
