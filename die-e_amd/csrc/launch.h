@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "search_types.h"
+
 namespace diee {
 
 // rules_kernels.hip
@@ -14,5 +16,26 @@ void launch_apply(hipStream_t st, void* states, const uint32_t* plays, const uin
 void launch_planes(hipStream_t st, const void* states, uint32_t n, float* out);
 void launch_probe_f32(hipStream_t st, const float* a, const float* b, uint32_t n, float* sq, float* dv, float* pw);
 void launch_probe_dice(hipStream_t st, uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni);
+
+// nn_kernels.hip
+void nn_setup_kernels();
+void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
+void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
+                    const uint16_t* res, uint16_t* out, float* out_v, int G, int N);
+void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
+void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
+                          float* value, int G);
+
+// mcts_kernels.hip
+void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
+void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks);
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P);
+void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits);
+void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed);
+void launch_gather_roots(hipStream_t st, const Games& G, const Slots& S, uint32_t n_live, uint32_t first_id);
+void launch_play_move(hipStream_t st, const Tree& T, const Games& G, uint32_t n_live, uint32_t step, const PlayParams& P);
+void launch_compact_live(hipStream_t st, const Games& G, uint32_t n_live, uint32_t* n_live_out);
+void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes);
+constexpr uint32_t kRootIteration = 0xFFFFFFFFu;
 
 }  // namespace diee

@@ -1,0 +1,454 @@
+// mcts_kernels.hip -- batched AlphaZero-style MCTS and the self-play move step for gfx950.
+//
+// Semantics follow the reference's src/mcts/alpha_mcts.rs:14-33,91-202, node.rs:98-112,157-174,
+// simple_mcts.rs:96-103, utils.rs:42-84, noise.rs:27-34 and src/alphazero/alpha_parallel.rs:
+// 129-229; the design does not: every live game owns a fixed-stride tree arena in HBM (SoA node
+// statistics, children contiguous), one wavefront walks / expands / backpropagates one game, and
+// an MCTS iteration is select kernel -> ResNet -> expand kernel with no host round trip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bg_device.h"
+#include "launch.h"
+#include "search_types.h"
+
+namespace diee {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kDrained = 0x80000000u;
+
+__device__ __forceinline__ uint32_t meta_nch(uint32_t m) { return (m >> 16) & 0x7fffu; }
+
+__device__ __forceinline__ BgState load_state(const BgState* p) {
+    BgState s;
+    const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
+    s.w[0] = a.x; s.w[1] = a.y; s.w[2] = a.z; s.w[3] = a.w;
+    s.w[4] = b.x; s.w[5] = b.y; s.w[6] = b.z; s.w[7] = b.w;
+    return s;
+}
+__device__ __forceinline__ void store_state(BgState* p, const BgState& s) {
+    ((uint4*)p)[0] = make_uint4(s.w[0], s.w[1], s.w[2], s.w[3]);
+    ((uint4*)p)[1] = make_uint4(s.w[4], s.w[5], s.w[6], s.w[7]);
+}
+
+// backpropagate, simple_mcts.rs:96-103: same sign at every level (one lane)
+__device__ __forceinline__ void backprop(const Tree& T, size_t base, uint32_t idx, float v) {
+    while (idx != kNone) {
+        T.visits[base + idx] += 1.0f;
+        T.value[base + idx] += v;
+        idx = T.parent[base + idx];
+    }
+}
+
+// ---- roots -------------------------------------------------------------------------------------
+// alpha_mcts.rs:110-112,123: one root node per state, visits = 1
+__global__ void k_init_roots(Tree T, Slots S, uint32_t n) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const size_t base = (size_t)slot * T.node_cap;
+    const BgState s = load_state(&S.roots[slot]);
+    store_state(&T.state[base], s);
+    store_state(&S.eval_states[slot], s);
+    T.visits[base] = 1.0f; T.value[base] = 0.0f; T.prior[base] = 0.0f;
+    T.parent[base] = kNone; T.first_child[base] = 0; T.meta[base] = 0xFFFFu;
+    T.used[slot] = 1;
+    S.sel[slot] = kNone; S.sel_value[slot] = 0.0f; S.leaf[slot] = 0; S.leaf_term[slot] = 0;
+}
+
+// ---- selection ---------------------------------------------------------------------------------
+struct Best { float s; int j; };
+__device__ __forceinline__ Best better(Best a, Best b) {      // later index wins ties (Iterator::max_by)
+    if (b.j < 0) return a;
+    if (a.j < 0) return b;
+    if (a.s > b.s || (a.s == b.s && a.j > b.j)) return a;
+    return b;
+}
+
+// alpha_select_leaf_node / select_alpha (alpha_mcts.rs:14-33) with alpha_ucb (node.rs:98-112):
+//   q + (c * (sqrt(N_parent) / (n + 1))) * p, f32, in this association; NaN compares Equal.
+__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)slot * T.node_cap;
+    uint32_t node = 0, depth = 0;
+    for (;;) {
+        const uint32_t k = meta_nch(T.meta[base + node]);
+        if (k == 0) break;
+        const uint32_t fc = T.first_child[base + node];
+        const float sq = sqrtf(T.visits[base + node]);
+        Best b{0.0f, -1};
+        int lastnan = -1;
+        for (uint32_t j = lane; j < k; j += 64) {
+            const size_t ci = base + fc + j;
+            const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
+            const float q = vis == 0.0f ? 0.0f : val / vis;
+            const float t = sq / (vis + 1.0f);
+            const float u = c * t;
+            const float w = u * pr;
+            const float s = q + w;
+            if (s != s) lastnan = (int)j;
+            else if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int ln = __shfl_xor(lastnan, d);
+            lastnan = ln > lastnan ? ln : lastnan;
+        }
+        if (lastnan >= 0) {
+            // the sequential fold restarts after a NaN: only children after the last NaN compete
+            b.s = 0.0f; b.j = -1;
+            for (uint32_t j = lane; j < k; j += 64) {
+                if ((int)j <= lastnan) continue;
+                const size_t ci = base + fc + j;
+                const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
+                const float q = vis == 0.0f ? 0.0f : val / vis;
+                const float t = sq / (vis + 1.0f);
+                const float u = c * t;
+                const float w = u * pr;
+                const float s = q + w;
+                if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            Best o;
+            o.s = __shfl_xor(b.s, d);
+            o.j = __shfl_xor(b.j, d);
+            b = better(b, o);
+        }
+        const int chosen = b.j >= 0 ? b.j : lastnan;       // lastnan == k-1 when nothing follows it
+        node = fc + (uint32_t)chosen;
+        ++depth;
+    }
+    const BgState st = load_state(&T.state[base + node]);
+    const int w = bg_winner_dev(st);
+    if (lane == 0) {
+        atomicAdd(&S.counters[CNT_SELECTIONS], 1ull);
+        atomicAdd(&S.counters[CNT_DEPTH_SUM], (unsigned long long)depth);
+        if (w != 0) {                                       // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
+            const BgState rs = load_state(&T.state[base]);
+            const float v = w == st_player(rs) ? 1.0f : -1.0f;
+            backprop(T, base, node, v);
+            S.leaf_term[slot] = 1;
+            atomicAdd(&S.counters[CNT_TERMINAL], 1ull);
+            if (quirks && S.sel[slot] == kNone) atomicAdd(&S.iter_flags[2 * it + 1], 1u);
+        } else {
+            S.leaf_term[slot] = 0; S.leaf[slot] = node; S.sel[slot] = node;
+            atomicOr(&S.iter_flags[2 * it], 1u);
+            store_state(&S.eval_states[slot], st);
+        }
+    }
+}
+
+// ---- expansion + backpropagation ---------------------------------------------------------------
+struct ExpandScratch {
+    WaveScratch ws;
+    float raw[kSeqCap];
+    uint16_t code[kSeqCap];
+    float sum;
+};
+
+// turn_policy_to_probs_tensor (utils.rs:74-84; root: utils.rs:60-72 on the Dirichlet-mixed policy,
+// noise.rs:27-34) + alpha_expand_tensor (node.rs:157-174).  it == kRootIt expands the roots.
+constexpr uint32_t kRootIt = 0xFFFFFFFFu;
+__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint32_t it, SearchParams P) {
+    __shared__ ExpandScratch sc;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)slot * T.node_cap;
+    const bool root = it == kRootIt;
+    const bool quirks = P.quirks != 0;
+    if (!root && S.iter_flags[2 * it] == 0) return;        // alpha_mcts.rs:170-172 `continue`
+    if (slot == 0 && lane == 0) atomicAdd(&S.counters[CNT_NN_EVALS], (unsigned long long)n);
+
+    uint32_t node = 0;
+    float v = 0.0f;
+    bool do_expand = true, do_backprop = !root;
+    if (!root) {
+        if (S.leaf_term[slot]) {
+            // stale selected_nodes_idxs slot (alpha_mcts.rs:142,192-200): re-"expanded" (no-op) and
+            // backpropagated with its own NN value again
+            do_expand = false; do_backprop = false;
+            if (quirks && lane == 0) {
+                const uint32_t s = S.sel[slot];
+                if (s != kNone) backprop(T, base, s, S.sel_value[slot]);
+            }
+        } else {
+            node = S.leaf[slot];
+            v = S.nn_value[slot];
+            if (lane == 0) S.sel_value[slot] = v;
+        }
+    } else if (slot == 0 && lane == 0) {
+        S.root_value0[0] = S.nn_value[0];
+    }
+    const uint32_t m0 = T.meta[base + node];
+    if (do_expand && !(m0 & kDrained)) {
+        const BgState st = load_state(&T.state[base + node]);
+        const int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
+        const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
+        const float* prow = S.policy + (size_t)slot * 1352;
+        const float om = 1.0f - P.dir_eps;
+        for (int j = lane; j < k; j += 64) {
+            const uint32_t play = sc.ws.play[j];
+            const uint32_t code = bg_encode_dev(r0, r1, play);
+            float p = prow[code];
+            if (root) {                                      // apply_dirichlet: (1-eps)*P + eps*noise
+                const float x = om * p, y = P.dir_eps * S.noise[code];
+                p = x + y;
+                if (bg_decode_dev(r0, r1, player, code) != play) atomicAdd(&S.counters[CNT_ILLEGAL], 1ull);
+            }
+            sc.raw[j] = p; sc.code[j] = (uint16_t)code;
+        }
+        __syncthreads();
+        if (lane == 0) {                                     // row sum, sequential in play order
+            float s = 0.0f;
+            for (int j = 0; j < k; ++j) s += sc.raw[j];
+            sc.sum = s;
+        }
+        __syncthreads();
+        const float sum = sc.sum;
+        const uint32_t first = T.used[slot];
+        if (first + (uint32_t)k > T.node_cap) {
+            if (lane == 0) atomicOr(S.overflow, 2u);
+        } else {
+            const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
+            const uint32_t e = root ? 0u : it + 1u;
+            for (int j = lane; j < k; j += 64) {
+                const size_t ci = base + first + j;
+                BgState cs = st;
+                int d0, d1;
+                draw_dice(P.seed, gid, rnd, e, (uint32_t)j, d0, d1);    // child dice frozen at creation (Q9)
+                bg_apply_dev(cs, sc.ws.play[j], d0, d1);
+                store_state(&T.state[ci], cs);
+                T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = sc.raw[j] / sum;
+                T.parent[ci] = node; T.first_child[ci] = 0; T.meta[ci] = sc.code[j];
+            }
+            if (lane == 0) {
+                T.first_child[base + node] = first;
+                T.meta[base + node] = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+                T.used[slot] = first + (uint32_t)k;
+                atomicAdd(&S.counters[CNT_EXPANSIONS], 1ull);
+                atomicAdd(&S.counters[CNT_CHILDREN], (unsigned long long)k);
+                atomicMax(&S.counters[CNT_MAX_CHILDREN], (unsigned long long)k);
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (do_backprop) backprop(T, base, node, v);
+        if (!root && quirks && slot == 0) {
+            // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
+            // i.e. this slot's root, with the NN value of its state
+            const uint32_t cnt = S.iter_flags[2 * it + 1];
+            const float rv = S.root_value0[0];
+            for (uint32_t i = 0; i < cnt; ++i) { T.visits[base] += 1.0f; T.value[base] += rv; }
+        }
+    }
+}
+
+// ---- get_prob_tensor_parallel, utils.rs:42-58 --------------------------------------------------
+__global__ __launch_bounds__(64) void k_root_probs(Tree T, uint32_t n, float* __restrict__ probs,
+                                                   uint32_t* __restrict__ nch, float* __restrict__ root_visits) {
+    __shared__ float sum_s;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)slot * T.node_cap;
+    const uint32_t k = meta_nch(T.meta[base]), fc = T.first_child[base];
+    float* row = probs + (size_t)slot * 1352;
+    const float fill = k == 0 ? __uint_as_float(0x7fc00000u) : 0.0f;       // 0/0 row
+    for (int a = lane; a < 1352; a += 64) row[a] = fill;
+    if (lane == 0) {
+        float s = 0.0f;
+        for (uint32_t j = 0; j < k; ++j) s += T.visits[base + fc + j];
+        sum_s = s;
+        nch[slot] = k;
+        if (root_visits) root_visits[slot] = T.visits[base];
+    }
+    __syncthreads();
+    const float sum = sum_s;
+    for (uint32_t j = lane; j < k; j += 64) row[T.meta[base + fc + j] & 0xFFFFu] = T.visits[base + fc + j] / sum;
+}
+
+// ---- self-play -----------------------------------------------------------------------------------
+// alpha_parallel.rs:103-111: T::new() + roll_die for every game
+__global__ void k_init_games(Games Gm, uint32_t n, uint32_t first_id, uint64_t seed) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    BgState s;
+    // Backgammon::new, backgammon_logic.rs:80-94
+    s.w[0] = 0x00000002u; s.w[1] = 0xFD00FB00u; s.w[2] = 0x05000000u; s.w[3] = 0x000000FBu;
+    s.w[4] = 0x00050003u; s.w[5] = 0xFE000000u; s.w[6] = 0u;
+    int d0, d1;
+    draw_dice(seed, first_id + g, 0u, kTagInitRoll, 0u, d0, d1);
+    s.w[7] = (uint32_t)d0 | ((uint32_t)d1 << 8) | (0xFFu << 16);
+    store_state(&Gm.state[g], s);
+    Gm.rounds[g] = 0; Gm.nfrags[g] = 0; Gm.alive[g] = 1; Gm.winner[g] = 0;
+    Gm.ev_a_count[g] = kNone; Gm.ev_b_count[g] = kNone; Gm.ev_a_step[g] = 0; Gm.ev_b_step[g] = 0;
+    Gm.live[g] = g;
+}
+
+__global__ void k_gather_roots(Games Gm, Slots S, uint32_t n_live, uint32_t first_id) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_live) return;
+    const uint32_t g = Gm.live[slot];
+    store_state(&S.roots[slot], load_state(&Gm.state[g]));
+    S.game_id[slot] = first_id + g;
+    S.round[slot] = Gm.rounds[g];
+}
+
+// the body of the per-game loop of self_play_parallel, alpha_parallel.rs:168-224
+__global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_live, uint32_t step, PlayParams P) {
+    __shared__ float row[1352];
+    __shared__ float sum_s;
+    __shared__ int chosen_s;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n_live) return;
+    const int lane = threadIdx.x;
+    const uint32_t g = Gm.live[slot];
+    const size_t base = (size_t)slot * T.node_cap;
+    const uint32_t k = meta_nch(T.meta[base]), fc = T.first_child[base];
+    BgState s = load_state(&Gm.state[g]);
+    const uint32_t round = Gm.rounds[g];
+    const uint32_t gid = P.first_id + g;
+    bool removed = false, flushed = false;
+    if (round >= P.round_limit) {                               // :172-180 (no `continue`)
+        if (lane == 0) { Gm.ev_a_count[g] = Gm.nfrags[g]; Gm.ev_a_step[g] = step; }
+        removed = true; flushed = true;
+    }
+    if (k == 0) {                                               // :183-189 skip_turn
+        if (lane == 0) {
+            int d0, d1;
+            draw_dice(P.seed, gid, round, kTagMoveRoll, 0u, d0, d1);
+            bg_skip_dev(s, d0, d1);
+            store_state(&Gm.state[g], s);
+            Gm.rounds[g] = round + 1;
+            if (removed) Gm.alive[g] = 0;
+            atomicAdd(&Gm.counters[CNT_PLIES], 1ull);
+        }
+        return;
+    }
+    // get_prob_tensor_parallel row (:164) and pow_(1/T) (:165), not renormalised (Q17)
+    for (int a = lane; a < 1352; a += 64) row[a] = 0.0f;
+    if (lane == 0) {
+        float sm = 0.0f;
+        for (uint32_t j = 0; j < k; ++j) sm += T.visits[base + fc + j];
+        sum_s = sm;
+    }
+    __syncthreads();
+    const float sum = sum_s;
+    for (uint32_t j = lane; j < k; j += 64)
+        row[T.meta[base + fc + j] & 0xFFFFu] = det_powf(T.visits[base + fc + j] / sum, P.inv_temperature);
+    __syncthreads();
+    // weighted_select_tensor_idx (alphazero.rs:129-137): rand WeightedIndex over f64 weights
+    if (lane == 0) {
+        double total = 0.0;
+        for (int a = 0; a < 1352; ++a) total += (double)row[a];
+        const double x = draw_uniform(P.seed, gid, round, kTagSample, 0u) * total;
+        double cum = 0.0;
+        int pick = -1, last_nz = 0;
+        for (int a = 0; a < 1352; ++a) {
+            if (row[a] != 0.0f) last_nz = a;
+            cum += (double)row[a];
+            if (cum > x) { pick = a; break; }
+        }
+        chosen_s = pick >= 0 ? pick : last_nz;
+    }
+    __syncthreads();
+    const uint32_t code = (uint32_t)chosen_s;
+    // MemoryFragment{outcome: player, ps, state} (:195-199)
+    const uint32_t nf = Gm.nfrags[g];
+    const size_t fi = (size_t)g * Gm.frag_cap + nf;
+    for (int a = lane; a < 1352; a += 64) Gm.frag_ps[fi * 1352 + a] = row[a];
+    for (int t = lane; t < 144; t += 64) Gm.frag_planes[fi * 144 + t] = bg_plane_dev(s, t / 24, t % 24);
+    if (lane == 0) {
+        Gm.frag_player[fi] = (int8_t)st_player(s);
+        Gm.nfrags[g] = nf + 1;
+        // decode + apply_move (:202-210); legality of decode(code) is checked when the root is expanded
+        const uint32_t play = bg_decode_dev(st_roll(s, 0), st_roll(s, 1), st_player(s), code);
+        int d0, d1;
+        draw_dice(P.seed, gid, round, kTagMoveRoll, 0u, d0, d1);
+        bg_apply_dev(s, play, d0, d1);
+        store_state(&Gm.state[g], s);
+        Gm.rounds[g] = round + 1;                               // :213
+        atomicAdd(&Gm.counters[CNT_PLIES], 1ull);
+        const int w = bg_winner_dev(s);
+        if (w != 0) {                                           // :215-223
+            if (!(flushed && !P.quirks)) { Gm.ev_b_count[g] = nf + 1; Gm.ev_b_step[g] = step; }
+            Gm.winner[g] = (int8_t)w;
+            removed = true;
+        }
+        if (removed) { Gm.alive[g] = 0; atomicAdd(&Gm.counters[CNT_GAMES], 1ull); }
+    }
+}
+
+// stable compaction of the live list (one block)
+__global__ __launch_bounds__(1024) void k_compact_live(Games Gm, uint32_t n_live, uint32_t* n_live_out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_live; c0 += 1024) {
+        const uint32_t i = c0 + tid;
+        uint32_t g = 0;
+        bool keep = false;
+        if (i < n_live) { g = Gm.live[i]; keep = Gm.alive[g] != 0; }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();                                        // all reads of live[c0..] done before writes
+        if (keep) Gm.live[pos] = g;
+        __syncthreads();
+        if (tid == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; carry += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *n_live_out = carry;
+}
+
+// gather fragments into the output order the host computed: src = g*frag_cap + r
+__global__ void k_gather_frags(Games Gm, const uint32_t* __restrict__ src, uint32_t n, float* __restrict__ ps,
+                               float* __restrict__ planes) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const size_t s = src[i];
+    for (int a = threadIdx.x; a < 1352; a += blockDim.x) ps[(size_t)i * 1352 + a] = Gm.frag_ps[s * 1352 + a];
+    for (int t = threadIdx.x; t < 144; t += blockDim.x) planes[(size_t)i * 144 + t] = Gm.frag_planes[s * 144 + t];
+}
+
+// ---- host launchers -----------------------------------------------------------------------------
+void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n) {
+    hipLaunchKernelGGL(k_init_roots, dim3((n + 255) / 256), dim3(256), 0, st, T, S, n);
+}
+void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
+    hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, n, it, c, quirks);
+}
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P) {
+    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, n, it, P);
+}
+void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits) {
+    hipLaunchKernelGGL(k_root_probs, dim3(n), dim3(64), 0, st, T, n, probs, nch, root_visits);
+}
+void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed) {
+    hipLaunchKernelGGL(k_init_games, dim3((n + 255) / 256), dim3(256), 0, st, G, n, first_id, seed);
+}
+void launch_gather_roots(hipStream_t st, const Games& G, const Slots& S, uint32_t n_live, uint32_t first_id) {
+    hipLaunchKernelGGL(k_gather_roots, dim3((n_live + 255) / 256), dim3(256), 0, st, G, S, n_live, first_id);
+}
+void launch_play_move(hipStream_t st, const Tree& T, const Games& G, uint32_t n_live, uint32_t step, const PlayParams& P) {
+    hipLaunchKernelGGL(k_play_move, dim3(n_live), dim3(64), 0, st, T, G, n_live, step, P);
+}
+void launch_compact_live(hipStream_t st, const Games& G, uint32_t n_live, uint32_t* n_live_out) {
+    hipLaunchKernelGGL(k_compact_live, dim3(1), dim3(1024), 0, st, G, n_live, n_live_out);
+}
+void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather_frags, dim3(n), dim3(256), 0, st, G, src, n, ps, planes);
+}
+
+}  // namespace diee

@@ -1,0 +1,243 @@
+// nn_host.cpp -- ResNet weights (blob layout of include/diee.h, BatchNorm folding, MFMA fragment
+// packing) and the forward pass driver.  Reference: src/alphazero/nnet.rs:57-133.
+#include <cmath>
+#include <cstring>
+
+#include "bg_device.h"
+#include "engine.h"
+#include "launch.h"
+#include "nn_host.h"
+
+namespace diee {
+
+namespace {
+
+constexpr int F = 256, BLOCKS = 19, A = 1352, CIN = 6, PH = 32, VH = 3;
+
+struct ConvOff { size_t w, b; int cout, cin; };
+struct BnOff { size_t g, b, m, v; int c; };
+struct BlobLayout {
+    ConvOff init_conv; BnOff init_bn;
+    ConvOff c1[BLOCKS], c2[BLOCKS]; BnOff b1[BLOCKS], b2[BLOCKS];
+    ConvOff p_conv; BnOff p_bn; size_t p_fcw, p_fcb;
+    ConvOff v_conv; BnOff v_bn; size_t v_fcw, v_fcb;
+    size_t total;
+};
+
+BlobLayout make_layout() {
+    BlobLayout L;
+    size_t off = 0;
+    auto conv = [&](int cout, int cin) { ConvOff c{off, 0, cout, cin}; off += (size_t)cout * cin * 9; c.b = off; off += cout; return c; };
+    auto bn = [&](int c) { BnOff b{off, off + c, off + 2 * (size_t)c, off + 3 * (size_t)c, c}; off += 4 * (size_t)c; return b; };
+    L.init_conv = conv(F, CIN); L.init_bn = bn(F);
+    for (int i = 0; i < BLOCKS; ++i) {            // ResBlock::new creation order, nnet.rs:38-45
+        L.c1[i] = conv(F, F); L.c2[i] = conv(F, F); L.b1[i] = bn(F); L.b2[i] = bn(F);
+    }
+    L.p_conv = conv(PH, F); L.p_bn = bn(PH); L.p_fcw = off; off += (size_t)A * PH * 24; L.p_fcb = off; off += A;
+    L.v_conv = conv(VH, F); L.v_bn = bn(VH); L.v_fcw = off; off += (size_t)VH * 24; L.v_fcb = off; off += 1;
+    L.total = off;
+    return L;
+}
+const BlobLayout& layout() { static const BlobLayout L = make_layout(); return L; }
+
+uint16_t f2bf_host(float x) {                       // round-to-nearest-even
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// fold eval-mode BatchNorm (eps 1e-5) into conv weight/bias: w' = w*s, b' = (b-mean)*s + beta
+void fold(const float* blob, const ConvOff& c, const BnOff& bn, std::vector<float>& w, std::vector<float>& b) {
+    w.assign((size_t)c.cout * c.cin * 9, 0.f); b.assign(c.cout, 0.f);
+    for (int n = 0; n < c.cout; ++n) {
+        const float s = blob[bn.g + n] / std::sqrt(blob[bn.v + n] + 1e-5f);
+        for (int k = 0; k < c.cin * 9; ++k) w[(size_t)n * c.cin * 9 + k] = blob[c.w + (size_t)n * c.cin * 9 + k] * s;
+        b[n] = (blob[c.b + n] - blob[bn.m + n]) * s + blob[bn.b + n];
+    }
+}
+
+// pack folded conv weights w[cout][cin][3][3] into MFMA B fragments:
+//   [nslice][kstep = cs*9 + tap][lane][j]:  n = nslice*32 + (lane&31),  c = cs*16 + 8*(lane>>5) + j
+void pack_conv(const std::vector<float>& w, int cout, int cin, int n_pad, int cin_pad, std::vector<uint16_t>& out) {
+    const int csteps = cin_pad / 16, ksteps = csteps * 9, nsl = n_pad / 32;
+    out.assign((size_t)nsl * ksteps * 64 * 8, 0);
+    for (int s = 0; s < nsl; ++s)
+        for (int cs = 0; cs < csteps; ++cs)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = s * 32 + (lane & 31), c = cs * 16 + 8 * (lane >> 5) + j;
+                        if (n >= cout || c >= cin) continue;
+                        out[(((size_t)s * ksteps + cs * 9 + t) * 64 + lane) * 8 + j] =
+                            f2bf_host(w[((size_t)n * cin + c) * 9 + t]);
+                    }
+}
+
+}  // namespace
+
+size_t weights_count_bg() { return layout().total; }
+
+// tch-default initialisation ([unvendored, from memory]): conv/linear weights
+// U(+-1/sqrt(fan_in)), conv bias 0, linear bias U(+-1/sqrt(fan_in)), BN gamma U(0,1), beta 0,
+// running mean 0, running var 1.  Philox keyed by (seed, tensor id): reproducible anywhere.
+void random_weights_bg(uint64_t seed, float* blob) {
+    const BlobLayout& L = layout();
+    uint32_t tid = 0;
+    auto uni = [&](size_t off, size_t n, float lo, float hi) {
+        for (size_t i = 0; i < n; i += 4) {
+            uint32_t o[4];
+            philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(i / 4), (uint32_t)((i / 4) >> 32), tid, 0x57E16u, o);
+            for (size_t k = 0; k < 4 && i + k < n; ++k)
+                blob[off + i + k] = lo + (hi - lo) * ((float)(o[k] >> 8) * (1.0f / 16777216.0f));
+        }
+        ++tid;
+    };
+    auto cst = [&](size_t off, size_t n, float v) { for (size_t i = 0; i < n; ++i) blob[off + i] = v; };
+    auto conv = [&](const ConvOff& c) {
+        const float bd = 1.0f / std::sqrt((float)(c.cin * 9));
+        uni(c.w, (size_t)c.cout * c.cin * 9, -bd, bd); cst(c.b, c.cout, 0.f);
+    };
+    auto bn = [&](const BnOff& b) { uni(b.g, b.c, 0.f, 1.f); cst(b.b, b.c, 0.f); cst(b.m, b.c, 0.f); cst(b.v, b.c, 1.f); };
+    conv(L.init_conv); bn(L.init_bn);
+    for (int i = 0; i < BLOCKS; ++i) { conv(L.c1[i]); conv(L.c2[i]); bn(L.b1[i]); bn(L.b2[i]); }
+    conv(L.p_conv); bn(L.p_bn);
+    { const float bd = 1.0f / std::sqrt((float)(PH * 24)); uni(L.p_fcw, (size_t)A * PH * 24, -bd, bd); uni(L.p_fcb, A, -bd, bd); }
+    conv(L.v_conv); bn(L.v_bn);
+    { const float bd = 1.0f / std::sqrt((float)(VH * 24)); uni(L.v_fcw, VH * 24, -bd, bd); uni(L.v_fcb, 1, -bd, bd); }
+}
+
+void free_net(NetWeights* n) { delete n; }
+
+void Engine::load_weights(const float* blob, size_t n) {
+    HIPCHK(hipSetDevice(device));
+    const BlobLayout& L = layout();
+    if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
+    if (!net) { net = new NetWeights(); nn_setup_kernels(); }
+    NetWeights& W = *net;
+    std::vector<float> w, b;
+    std::vector<uint16_t> pk;
+    auto up_conv = [&](int layer, const ConvOff& c, const BnOff& bn, int n_pad, int cin_pad) {
+        fold(blob, c, bn, w, b);
+        pack_conv(w, c.cout, c.cin, n_pad, cin_pad, pk);
+        W.wconv[layer].ensure(pk.size());
+        h2d(W.wconv[layer].p, pk.data(), pk.size());
+        std::vector<float> bp(n_pad, 0.f);
+        memcpy(bp.data(), b.data(), sizeof(float) * c.cout);
+        W.bconv[layer].ensure(n_pad);
+        h2d(W.bconv[layer].p, bp.data(), (size_t)n_pad);
+        sync();     // pk / bp are reused
+    };
+    up_conv(0, L.init_conv, L.init_bn, 256, 16);
+    for (int i = 0; i < BLOCKS; ++i) { up_conv(1 + 2 * i, L.c1[i], L.b1[i], 256, 256); up_conv(2 + 2 * i, L.c2[i], L.b2[i], 256, 256); }
+    {   // heads share one conv launch: channels 0..31 policy (nnet.rs:76), 32..34 value (nnet.rs:88)
+        std::vector<float> wp, bp, wv, bv;
+        fold(blob, L.p_conv, L.p_bn, wp, bp); fold(blob, L.v_conv, L.v_bn, wv, bv);
+        w.assign((size_t)35 * F * 9, 0.f); b.assign(35, 0.f);
+        memcpy(w.data(), wp.data(), sizeof(float) * wp.size()); memcpy(w.data() + wp.size(), wv.data(), sizeof(float) * wv.size());
+        memcpy(b.data(), bp.data(), sizeof(float) * 32); memcpy(b.data() + 32, bv.data(), sizeof(float) * 3);
+        pack_conv(w, 35, F, 128, 256, pk);
+        W.wconv[39].ensure(pk.size()); h2d(W.wconv[39].p, pk.data(), pk.size());
+        std::vector<float> bpad(128, 0.f); memcpy(bpad.data(), b.data(), sizeof(float) * 35);
+        W.bconv[39].ensure(128); h2d(W.bconv[39].p, bpad.data(), (size_t)128);
+        sync();
+    }
+    {   // policy FC [1352][768], reference k = c*24 + p (flatten of [32][4][6], nnet.rs:79); ours k' = p*32 + c
+        const int nsl = 43, ksteps = 48;
+        pk.assign((size_t)nsl * ksteps * 64 * 8, 0);
+        for (int s = 0; s < nsl; ++s)
+            for (int ks = 0; ks < ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int a = s * 32 + (lane & 31), kp = ks * 16 + 8 * (lane >> 5) + j;
+                        if (a >= A) continue;
+                        const int p = kp / 32, c = kp % 32;
+                        pk[(((size_t)s * ksteps + ks) * 64 + lane) * 8 + j] = f2bf_host(blob[L.p_fcw + (size_t)a * 768 + c * 24 + p]);
+                    }
+        W.wfc.ensure(pk.size()); h2d(W.wfc.p, pk.data(), pk.size());
+        std::vector<float> bf(1376, 0.f); memcpy(bf.data(), blob + L.p_fcb, sizeof(float) * A);
+        W.bfc.ensure(1376); h2d(W.bfc.p, bf.data(), (size_t)1376);
+        std::vector<float> wv(73, 0.f);             // value FC, ours k' = p*3 + c
+        for (int p = 0; p < 24; ++p) for (int c = 0; c < 3; ++c) wv[p * 3 + c] = blob[L.v_fcw + c * 24 + p];
+        wv[72] = blob[L.v_fcb];
+        W.wv.ensure(73); h2d(W.wv.p, wv.data(), (size_t)73);
+        sync();
+    }
+    W.loaded = true;
+}
+
+void nn_reserve(Engine& e, int G) {
+    NetWeights& W = *e.net;
+    if (G <= W.cap_games) return;
+    const size_t Gp = (size_t)((G + 7) / 8 * 8), M = Gp * 24;
+    W.x16.ensure(M * 16); W.actX.ensure(M * 256); W.actH.ensure(M * 256);
+    W.hp.ensure(Gp * 768); W.hv.ensure(Gp * 72); W.logits.ensure(Gp * 1352);
+    W.cap_games = (int)Gp;
+}
+
+// forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh)
+void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev) {
+    if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    if (G <= 0) return;
+    NetWeights& W = *e.net;
+    nn_reserve(e, G);
+    hipStream_t st = e.stream;
+    const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
+    launch_planes_bf16(st, states_dev, (uint32_t)G, W.x16.p);
+    launch_conv3x3(st, 16, 0, W.x16.p, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+    for (int i = 0; i < BLOCKS; ++i) {
+        for (int half = 0; half < 2; ++half) {
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
+            if (half == 0)
+                launch_conv3x3(st, 256, 0, W.actX.p, W.wconv[1 + 2 * i].p, W.bconv[1 + 2 * i].p, nullptr, W.actH.p, nullptr, G, 256);
+            else    // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
+                launch_conv3x3(st, 256, 1, W.actH.p, W.wconv[2 + 2 * i].p, W.bconv[2 + 2 * i].p, W.actX.p, W.actX.p, nullptr, G, 256);
+            if (sample) {
+                HIPCHK(hipEventRecord(ev1, st));
+                W.pending.push_back({ev0, ev1, 2.0 * G * 24.0 * 2304.0 * 256.0});
+            }
+        }
+    }
+    launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 128);
+    launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
+    launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
+    HIPCHK(hipGetLastError());
+}
+
+// harvest sampled conv timings (call after a stream sync)
+void nn_harvest(Engine& e, diee_stats* stats) {
+    if (!e.net) return;
+    NetWeights& W = *e.net;
+    for (auto& p : W.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            W.conv_seconds += ms * 1e-3; W.conv_launches += 1; W.conv_flops += p.flops;
+        }
+        W.free_events.push_back(p.a); W.free_events.push_back(p.b);
+    }
+    W.pending.clear();
+    if (stats) { stats->conv_seconds = W.conv_seconds; stats->conv_launches = W.conv_launches; stats->conv_flops = W.conv_flops; }
+}
+void nn_reset_timing(Engine& e) {
+    if (!e.net) return;
+    e.net->conv_seconds = 0; e.net->conv_launches = 0; e.net->conv_flops = 0; e.net->forward_count = 0;
+}
+
+void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* policy, float* value) {
+    HIPCHK(hipSetDevice(device));
+    if (!net || !net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    if (!n) return;
+    tmp_a.ensure((size_t)n * 32);
+    tmp_b.ensure((size_t)n * 1352 * 4);
+    tmp_c.ensure((size_t)n * 4);
+    h2d(tmp_a.p, (const uint8_t*)states, (size_t)n * 32);
+    const int se = net->sample_every; net->sample_every = 0;
+    nn_forward(*this, tmp_a.p, (int)n, (float*)tmp_b.p, (float*)tmp_c.p);
+    net->sample_every = se;
+    d2h((uint8_t*)policy, tmp_b.p, (size_t)n * 1352 * 4);
+    d2h((uint8_t*)value, tmp_c.p, (size_t)n * 4);
+    sync();
+}
+
+}  // namespace diee

@@ -1,0 +1,262 @@
+// nn_kernels.hip -- policy/value ResNet inference (reference: src/alphazero/nnet.rs:24-34,57-107,
+// 120-155, eval-mode BatchNorm folded) as hand-written bf16 MFMA kernels for gfx950.
+//
+// conv3x3 (the hot kernel): implicit GEMM  out[M=G*24][N] = sum over 9 taps of shift_t(act)[M][C] x W_t[C][N].
+//   * one workgroup = kGames whole boards (192 rows) x 128 output channels, 4 waves, one per SIMD;
+//   * the activation tile (all C_IN channels of the 8 boards) is staged ONCE into LDS (padded rows:
+//     conflict-free ds_read_b128) and stays stationary: the 9 taps re-read it at row offsets, board
+//     borders are redirected to a zero row (per-lane addresses precomputed, no masking in the loop);
+//   * the weights are pre-packed on the host in MFMA B-fragment order and streamed straight from
+//     L2 into registers (1 KiB coalesced per wave-instruction), prefetched one channel-step ahead;
+//     no barrier inside the K loop;
+//   * v_mfma_f32_32x32x16_bf16, 6 M-fragments x 1 N-fragment per wave: 96 accumulator registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bg_device.h"
+#include "launch.h"
+
+namespace diee {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+constexpr int kGames = 8;                  // boards per workgroup
+constexpr int kRows = kGames * 24;         // 192 GEMM rows per workgroup
+constexpr int kMFrags = kRows / 32;        // 6
+
+__device__ __forceinline__ uint16_t f2bf(float x) {
+    const __bf16 b = (__bf16)x;            // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// NN input: as_tensor planes (backgammon_logic.rs:198-252) as bf16 NHWC rows [g*24+p][16] (6 real
+// channels, 10 zero): small integers, exact in bf16.
+__global__ void k_planes_bf16(const BgState* __restrict__ states, uint32_t n, uint16_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (state, point)
+    if (i >= n * 24u) return;
+    const BgState s = states[i / 24u];
+    const int p = (int)(i % 24u);
+    uint32_t w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t lo = 2 * c < 6 ? f2bf(bg_plane_dev(s, 2 * c, p)) : 0u;
+        const uint32_t hi = 2 * c + 1 < 6 ? f2bf(bg_plane_dev(s, 2 * c + 1, p)) : 0u;
+        w[c] = lo | (hi << 16);
+    }
+    u32x4* o = (u32x4*)(out + (size_t)i * 16);
+    o[0] = u32x4{w[0], w[1], w[2], w[3]};
+    o[1] = u32x4{w[4], w[5], w[6], w[7]};
+}
+
+// MODE 0: out = relu(conv + bias)          (init block, ResBlock conv1; nnet.rs:26-28, 64-67)
+// MODE 1: out = relu(conv + bias + res)    (ResBlock conv2 + skip;      nnet.rs:29-33)
+// MODE 2: heads: channels 0..31 -> policy features bf16 [g][p*32+c], 32..34 -> value features f32
+//         [g][p*3+c], both after ReLU       (nnet.rs:75-79, 87-91)
+template <int C_IN, int MODE>
+__global__ __launch_bounds__(256) void k_conv3x3(const uint16_t* __restrict__ act,      // [M][C_IN] bf16
+                                                 const u32x4* __restrict__ wpack,      // [N/32][KSTEPS][64] x 16 B
+                                                 const float* __restrict__ bias,       // [N]
+                                                 const uint16_t* __restrict__ res,     // [M][N] bf16 (MODE 1)
+                                                 uint16_t* __restrict__ out,           // [M][N] bf16 / policy feats
+                                                 float* __restrict__ out_v,            // value feats (MODE 2)
+                                                 int M, int N) {
+    constexpr int RS = C_IN * 2 + 16;              // LDS row stride (bytes): +16 B pad => conflict-free b128
+    constexpr int CPR = C_IN * 2 / 16;             // 16-B chunks per row
+    constexpr int CSTEPS = C_IN / 16;              // channel steps of 16
+    constexpr int KSTEPS = CSTEPS * 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * kRows;
+    const int nslice = blockIdx.y * 4 + wave;      // 32 output channels per wave
+
+    // ---- stage the activation tile (whole boards, all input channels) ----
+    for (int i = tid; i < kRows * CPR; i += 256) {
+        const int r = i / CPR, ch = i % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
+        *(u32x4*)(smem + r * RS + ch * 16) = v;
+    }
+    if (tid < CPR + 1) *(u32x4*)(smem + kRows * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};   // zero row
+    // per-lane LDS byte addresses of the A fragments: [tap][M-fragment]
+    int base[9][kMFrags];
+#pragma unroll
+    for (int f = 0; f < kMFrags; ++f) {
+        const int R = 32 * f + (lane & 31);
+        const int p = R % 24, y = p / 6, x = p % 6;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            const int src = ok ? R + 6 * dy + dx : kRows;
+            base[t][f] = src * RS + (lane >> 5) * 16;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[kMFrags];
+#pragma unroll
+    for (int f = 0; f < kMFrags; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+
+    const u32x4* wp = wpack + (size_t)nslice * KSTEPS * 64 + lane;
+    u32x4 bq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bq[t] = wp[t * 64];
+
+    for (int cs = 0; cs < CSTEPS; ++cs) {
+        const int nxt = (cs + 1 < CSTEPS ? cs + 1 : cs) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[t]);
+            bq[t] = wp[(nxt + t) * 64];                       // prefetch the same tap of the next channel step
+#pragma unroll
+            for (int f = 0; f < kMFrags; ++f) {
+                const bf16x8 a = *(const bf16x8*)(smem + base[t][f] + cs * 32);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[f], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
+    const int n = nslice * 32 + (lane & 31);
+    const float bv = bias[n];
+#pragma unroll
+    for (int f = 0; f < kMFrags; ++f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = row0 + 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            if (r >= M) continue;
+            float v = acc[f][i] + bv;
+            if (MODE == 1) v += bf2f(res[(size_t)r * N + n]);
+            v = v > 0.0f ? v : 0.0f;
+            if (MODE == 2) {
+                const int g = r / 24, p = r % 24;
+                if (n < 32) out[(size_t)g * 768 + p * 32 + n] = f2bf(v);
+                else if (n < 35) out_v[(size_t)g * 72 + p * 3 + (n - 32)] = v;
+            } else {
+                out[(size_t)r * N + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+// policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight
+// from L2 (the layer is ~0.2 % of the network's FLOPs).
+__global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
+                                                  const u32x4* __restrict__ wpack,   // [43][48][64] x 16 B
+                                                  const float* __restrict__ bias,    // [1376]
+                                                  float* __restrict__ logits,        // [G][1352]
+                                                  int G) {
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 32, nslice = blockIdx.y;
+    int row = g0 + (lane & 31);
+    const bool rok = row < G;
+    if (!rok) row = G - 1;
+    const uint16_t* ap = hp + (size_t)row * 768 + (lane >> 5) * 8;
+    const u32x4* wp = wpack + (size_t)nslice * 48 * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll 8
+    for (int ks = 0; ks < 48; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(ap + ks * 16);
+        const bf16x8 b = __builtin_bit_cast(bf16x8, wp[ks * 64]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    const int n = nslice * 32 + (lane & 31);
+    if (n >= 1352) return;
+    const float bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int g = g0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (g < G) logits[(size_t)g * 1352 + n] = acc[i] + bv;
+    }
+}
+
+// softmax over the 1352 logits (nnet.rs:126-128) + value FC 72 -> 1 + tanh (nnet.rs:92-98): one wave per game
+__global__ __launch_bounds__(64) void k_softmax_value(const float* __restrict__ logits, const float* __restrict__ hv,
+                                                      const float* __restrict__ wv /* [72] + bias */,
+                                                      float* __restrict__ policy, float* __restrict__ value, int G) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= G) return;
+    const float* lr = logits + (size_t)g * 1352;
+    float v[22];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) {
+        const int a = lane + 64 * j;
+        v[j] = a < 1352 ? lr[a] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) {
+        v[j] = lane + 64 * j < 1352 ? expf(v[j] - mx) : 0.0f;
+        sum += v[j];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 22; ++j) {
+        const int a = lane + 64 * j;
+        if (a < 1352) policy[(size_t)g * 1352 + a] = v[j] * inv;
+    }
+    float dot = 0.0f;
+    for (int k = lane; k < 72; k += 64) dot += hv[(size_t)g * 72 + k] * wv[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+    if (lane == 0) value[g] = tanhf(dot + wv[72]);
+}
+
+// ---- host launchers -----------------------------------------------------------------------------
+static int lds_bytes(int c_in) { return (kRows + 1) * (c_in * 2 + 16) + 16 * 2; }
+
+void nn_setup_kernels() {
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(16));
+}
+
+void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_planes_bf16, dim3((n * 24 + 255) / 256), dim3(256), 0, st, (const BgState*)states, n, out);
+}
+
+// mode: 0 relu(conv+b), 1 relu(conv+b+res), 2 heads; c_in 16 (init block, 6 real channels) or 256
+void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
+                    const uint16_t* res, uint16_t* out, float* out_v, int G, int N) {
+    if (G <= 0) return;
+    const dim3 grid((G + kGames - 1) / kGames, N / 128), block(256);
+    const int M = G * 24;
+    const size_t lds = (size_t)lds_bytes(c_in);
+    if (c_in == 16)
+        hipLaunchKernelGGL((k_conv3x3<16, 0>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
+    else if (mode == 0)
+        hipLaunchKernelGGL((k_conv3x3<256, 0>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_conv3x3<256, 1>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
+    else
+        hipLaunchKernelGGL((k_conv3x3<256, 2>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
+}
+
+void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G) {
+    if (G <= 0) return;
+    hipLaunchKernelGGL(k_policy_fc, dim3((G + 31) / 32, 43), dim3(64), 0, st, hp, (const u32x4*)wpack, bias, logits, G);
+}
+
+void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
+                          float* value, int G) {
+    if (G <= 0) return;
+    hipLaunchKernelGGL(k_softmax_value, dim3(G), dim3(64), 0, st, logits, hv, wv, policy, value, G);
+}
+
+}  // namespace diee

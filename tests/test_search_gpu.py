@@ -1,0 +1,109 @@
+"""GPU parity of the batched MCTS and of self-play: the HIP path (through the C ABI) against the CPU
+oracle's restatement of alpha_mcts_parallel / self_play_parallel.  The oracle's evaluator is the
+engine's own ResNet (called back through diee_nn_forward), so priors and values are identical on both
+sides and every tree statistic, policy target and game record must agree BIT-EXACTLY."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xD1EE0001
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    yield e
+    e.close()
+
+
+def gpu_eval(eng, oracle):
+    calls = {"n": 0}
+
+    def fn(states_u8):
+        calls["n"] += 1
+        st = states_u8.view(oracle.BG_STATE).reshape(-1)
+        return eng.forward_t(st)
+    return oracle.make_eval(fn, 1352), calls
+
+
+def cfgs(oracle, iters, **kw):
+    import diee_amd
+    d = dict(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25); d.update(kw)
+    return oracle.MctsCfg(**d), diee_amd.MctsConfig(**d)
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+@pytest.mark.parametrize("n,iters,pick", [(8, 24, "opening"), (24, 40, "mid"), (16, 30, "late"), (1, 16, "mid")])
+def test_mcts_batch_bit_exact(eng, oracle, n, iters, pick, quirks):
+    walk = oracle.random_walk_states(77, 40)
+    if pick == "opening":
+        states = walk[:n]
+    elif pick == "mid":
+        states = walk[200:200 + 7 * n:7]
+    else:   # late: positions close to the end of games (terminal leaves, stale-slot quirk, bear-off)
+        off = walk["off"].max(axis=1)
+        states = walk[off >= 12][:n]
+    assert len(states) == n
+    ocfg, gcfg = cfgs(oracle, iters)
+    ev, _ = gpu_eval(eng, oracle)
+    gids = np.arange(100, 100 + n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 5
+    roots, probs, ostats, n_nodes = oracle.alpha_mcts_parallel(1, states, ocfg, ev, None, SEED, 3, gids, rds, quirks)
+    r = eng.alpha_mcts_parallel(states, gcfg, SEED, 3, gids, rds, ref_quirks=bool(quirks))
+    onch = np.array([len(x["children"]) for x in roots], dtype=np.uint32)
+    assert (r["n_children"] == onch).all()
+    assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all()
+    assert r["probs"].tobytes() == probs.tobytes(), np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max()
+    gs, os_ = r["stats"], ostats.as_dict()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert gs[key] == os_[key], (key, gs[key], os_[key])
+    assert gs["illegal_decodes"] == 0 and os_["code_collisions"] == 0
+    if pick == "late":
+        assert os_["terminal_hits"] > 0          # the terminal / stale-slot paths were exercised
+
+
+def test_self_play_bit_exact(eng, oracle):
+    """whole games: records, policy targets (visits/sum)^(1/T) and outcomes identical to the oracle"""
+    n, iters = 12, 12
+    ocfg, gcfg = cfgs(oracle, iters, round_limit=60)     # a low round limit exercises the Q18 flush too
+    ev, calls = gpu_eval(eng, oracle)
+    ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED, ev, None, ref_quirks=1, first_game_id=5)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED, ref_quirks=True, first_game_id=5)
+    assert out["stats"]["move_steps"] == ref["steps"]
+    assert len(out["outcome"]) == len(ref["outcome"]) > 0
+    assert (out["game"] == ref["game"]).all()
+    assert (out["outcome"] == ref["outcome"]).all()
+    assert out["state"].tobytes() == ref["state"].tobytes()
+    assert out["ps"].tobytes() == ref["ps"].tobytes()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections"):
+        assert out["stats"][key] == ref["stats"][key], key
+    assert out["stats"]["plies"] == int(ref["plies"].sum())
+    assert out["stats"]["games"] == n
+    assert out["stats"]["illegal_decodes"] == 0 == ref["stats"]["illegal_decodes"]
+    # invariants of the records (tests/mcts_test.rs:40-60 row-sum property, before the temperature)
+    ps = out["ps"].astype(np.float64)
+    assert np.allclose((ps ** 1.25).sum(1), 1.0, atol=1e-5)
+    assert set(np.unique(out["outcome"])) <= {-1, 0, 1}
+
+
+def test_self_play_plays_to_completion(eng, oracle):
+    """full-length games, no round limit pressure: every game ends with a winner and +-1 labels"""
+    import diee_amd
+    n = 16
+    _, gcfg = cfgs(oracle, 16)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 1, ref_quirks=True)
+    st = out["stats"]
+    assert st["games"] == n and st["fragments"] == len(out["outcome"])
+    assert (np.bincount(out["game"], minlength=n) > 0).all()
+    assert set(np.unique(out["outcome"])) <= {-1, 1}
+    # every recorded state is a legal NN input of its game: player plane constant +-1
+    pl = out["state"].reshape(-1, 6, 24)[:, 1, :]
+    assert (np.abs(pl) == 1).all() and (pl == pl[:, :1]).all()
+    # the label is +1 exactly when the mover of that state is the winner: within a game the sign flips with the mover
+    for g in range(n):
+        m = out["game"] == g
+        assert (out["outcome"][m] * pl[m, 0] == (out["outcome"][m] * pl[m, 0])[0]).all()
