@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play throughput of the MI355X-native die-e engine (BASELINE.json metric).
+
+One "step" = one complete self_play_parallel batch (alpha_parallel.rs:101-231): 1024 backgammon
+games per GPU played to completion with iterations=100 MCTS and a random-init 19-block ResNet
+(BASELINE.json configs[1]).  `value` = games retired by all ranks / wall time of the K timed
+steps, inputs (weights, game states) resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--iterations I]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: games are independent, so ranks are independent data-parallel workers (weak scaling,
+no data-path collective); torch.distributed (RCCL) only provides the barrier and the max/sum of
+the per-rank timings and counters.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOPS_PER_EVAL = 1_082_450_064
+
+
+def cpu_baseline(n_games, iterations, max_steps, seed, exp_per_game):
+    """the CPU oracle (C restatement of the reference's serial tree loops) + PyTorch fp32 CPU ResNet
+    (what tch/libtorch gives the reference on a CPU-only host), on a bounded sample"""
+    import numpy as np
+    import torch
+    import diee_amd
+    from oracle import oracle as orc
+    from oracle import nn_ref
+    orc.build()
+    net = nn_ref.parse(diee_amd.random_weights(0))
+    cores = torch.get_num_threads()
+
+    def fn(states_u8):
+        st = states_u8.view(orc.BG_STATE).reshape(-1)
+        pol, val, _ = nn_ref.forward_t(net, orc.planes_batch(st))
+        return pol, val
+    ev = orc.make_eval(fn, 1352)
+    cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    t = time.time()
+    r = orc.self_play_parallel(1, n_games, cfg, 1.25, seed, ev, None, ref_quirks=1, max_steps=max_steps)
+    dt = time.time() - t
+    exps = r["stats"]["expansions"]
+    return {
+        "value": (exps / dt) / exp_per_game if exp_per_game else None, "unit": "games/s",
+        "expansions_per_s": exps / dt, "cores": cores, "kind": "port",
+        "sample": f"oracle (single-threaded C tree/game logic) + PyTorch fp32 CPU ResNet ({cores} intra-op threads): "
+                  f"{n_games} games x {max_steps} move-steps, iterations={iterations}, {exps} expansions in {dt:.1f} s; "
+                  f"games/s extrapolated with the GPU run's {exp_per_game:.0f} expansions per game",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--games", type=int, default=1024, help="num_self_play_batches per GPU")
+    ap.add_argument("--iterations", type=int, default=100)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")            # "nccl" is RCCL on ROCm
+
+    import diee_amd
+    eng = diee_amd.Engine(local_rank)              # raises without a GPU: there is no CPU path
+    eng.load_weights(diee_amd.random_weights(0))
+    cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    first_id = rank * args.games
+    # primer (not a step): pages in the code objects and sizes the HBM arenas
+    eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=False)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_step(i):
+        return eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
+                                      first_game_id=first_id, fetch=False)["stats"]
+
+    for i in range(args.warmup):
+        run_step(1000 + i)
+    barrier()
+    t0 = time.perf_counter()
+    tot = {}
+    for i in range(args.steps):
+        st = run_step(i)                            # the call returns after the stream has drained
+        for k, v in st.items():
+            tot[k] = tot.get(k, 0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+
+    keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
+            "conv_seconds", "conv_launches", "conv_flops", "fragments", "illegal_decodes"]
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        vec = torch.tensor([float(tot[k]) for k in keys], dtype=torch.float64, device="cuda")
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        tot.update({k: float(v) for k, v in zip(keys, vec.tolist())})
+
+    if rank == 0:
+        games = tot["games"]
+        exp_per_game = tot["expansions"] / max(games, 1)
+        achieved = tot["conv_flops"] / tot["conv_seconds"] / 1e12 if tot["conv_seconds"] else None
+        out = {
+            "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"backgammon self_play_parallel, num_self_play_batches={args.games} per GPU, "
+                                   f"iterations={args.iterations}, exploration_const=2, temperature=1.25, "
+                                   "simulate_round_limit=400, dirichlet 0.3/0.25, random-init 19x256 ResNet (seed 0), "
+                                   "ref_quirks on", "parallelism": f"dp{world} (independent games, no collective)"},
+            "node_expansions_per_s": tot["expansions"] / dt,
+            "nn_evals_per_s": tot["nn_evals"] / dt,
+            "mfma_fraction_end_to_end": tot["nn_evals"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "stats": {"games": games, "plies_per_game": tot["plies"] / max(games, 1), "move_steps": tot["move_steps"],
+                      "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
+                      "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
+                      "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"]},
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<256,*> (3x3 tower conv, implicit GEMM)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS if achieved else None, "traffic": None,
+                         "launches_sampled": tot["conv_launches"] / world,
+                         "avg_launch_us": tot["conv_seconds"] / max(tot["conv_launches"], 1) * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(8, args.iterations, 2, args.seed, exp_per_game)
+            except Exception as e:                   # the baseline is a report, never a reason to lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 // diee_api.cpp -- C ABI (include/diee.h) and host-side engine of libdiee.so.
 #include "../../include/diee.h"
 #include "engine.h"
+#include "nn_host.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -152,6 +153,14 @@ diee_status diee_self_play(diee_ctx* c, uint32_t n_games, uint32_t first_game_id
     API_BEGIN(c)
     if (!cfg || n_games == 0) throw EngineError(DIEE_ERR_ARG, "bad arguments");
     c->self_play(n_games, first_game_id, cfg, temperature, seed, flags, max_steps, out, stats);
+    API_END(c)
+}
+
+diee_status diee_dev_conv_bench(diee_ctx* c, int G, int variant, int reps, float* us_mode0, float* us_mode1,
+                                float* us_forward) {
+    API_BEGIN(c)
+    HIPCHK(hipSetDevice(c->device));
+    nn_conv_bench(*c, G, variant, reps, us_mode0, us_mode1, us_forward);
     API_END(c)
 }
 

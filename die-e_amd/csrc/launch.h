@@ -19,6 +19,7 @@ void launch_probe_dice(hipStream_t st, uint64_t seed, const uint32_t* ctr, uint3
 
 // nn_kernels.hip
 void nn_setup_kernels();
+void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geometry (development)
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
                     const uint16_t* res, uint16_t* out, float* out_v, int G, int N);

@@ -136,10 +136,10 @@ void Engine::load_weights(const float* blob, size_t n) {
         w.assign((size_t)35 * F * 9, 0.f); b.assign(35, 0.f);
         memcpy(w.data(), wp.data(), sizeof(float) * wp.size()); memcpy(w.data() + wp.size(), wv.data(), sizeof(float) * wv.size());
         memcpy(b.data(), bp.data(), sizeof(float) * 32); memcpy(b.data() + 32, bv.data(), sizeof(float) * 3);
-        pack_conv(w, 35, F, 128, 256, pk);
+        pack_conv(w, 35, F, 64, 256, pk);
         W.wconv[39].ensure(pk.size()); h2d(W.wconv[39].p, pk.data(), pk.size());
-        std::vector<float> bpad(128, 0.f); memcpy(bpad.data(), b.data(), sizeof(float) * 35);
-        W.bconv[39].ensure(128); h2d(W.bconv[39].p, bpad.data(), (size_t)128);
+        std::vector<float> bpad(64, 0.f); memcpy(bpad.data(), b.data(), sizeof(float) * 35);
+        W.bconv[39].ensure(64); h2d(W.bconv[39].p, bpad.data(), (size_t)64);
         sync();
     }
     {   // policy FC [1352][768], reference k = c*24 + p (flatten of [32][4][6], nnet.rs:79); ours k' = p*32 + c
@@ -199,7 +199,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
             }
         }
     }
-    launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 128);
+    launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
     launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
@@ -222,6 +222,48 @@ void nn_harvest(Engine& e, diee_stats* stats) {
 void nn_reset_timing(Engine& e) {
     if (!e.net) return;
     e.net->conv_seconds = 0; e.net->conv_launches = 0; e.net->conv_flops = 0; e.net->forward_count = 0;
+}
+
+// development probe: average device time of the tower conv kernel (modes 0 and 1) at batch G
+void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward) {
+    if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    NetWeights& W = *e.net;
+    nn_reserve(e, G);
+    hipStream_t st = e.stream;
+    const size_t M = (size_t)((G + 7) / 8 * 8) * 24;
+    HIPCHK(hipMemsetAsync(W.actX.p, 0x3c, M * 256 * 2, st));     // bf16 0x3c3c ~ 0.0115
+    HIPCHK(hipMemsetAsync(W.actH.p, 0x3c, M * 256 * 2, st));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    nn_set_conv_variant(variant);
+    float ms = 0.f;
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int r = -3; r < reps; ++r) {
+            if (r == 0) HIPCHK(hipEventRecord(a, st));
+            const int layer = 1 + ((r + 3) % 38);
+            launch_conv3x3(st, 256, mode, mode ? W.actH.p : W.actX.p, W.wconv[layer].p, W.bconv[layer].p,
+                           mode ? W.actX.p : nullptr, mode ? W.actX.p : W.actH.p, nullptr, G, 256);
+        }
+        HIPCHK(hipEventRecord(b, st));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        (mode ? *us_mode1 : *us_mode0) = ms * 1e3f / reps;
+    }
+    // whole forward (device-resident inputs)
+    e.tmp_a.ensure((size_t)G * 32); e.tmp_b.ensure((size_t)G * 1352 * 4); e.tmp_c.ensure((size_t)G * 4);
+    HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
+    const int se = W.sample_every; W.sample_every = 0;
+    for (int r = -2; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(a, st));
+        nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
+    }
+    W.sample_every = se;
+    HIPCHK(hipEventRecord(b, st));
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *us_forward = ms * 1e3f / reps;
+    nn_set_conv_variant(0);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
 }
 
 void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* policy, float* value) {

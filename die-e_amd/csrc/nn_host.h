@@ -38,5 +38,6 @@ void nn_reserve(Engine& e, int G);
 void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev);
 void nn_harvest(Engine& e, diee_stats* stats);
 void nn_reset_timing(Engine& e);
+void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward);
 
 }  // namespace diee

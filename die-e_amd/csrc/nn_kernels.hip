@@ -22,9 +22,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int kGames = 8;                  // boards per workgroup
-constexpr int kRows = kGames * 24;         // 192 GEMM rows per workgroup
-constexpr int kMFrags = kRows / 32;        // 6
 
 __device__ __forceinline__ uint16_t f2bf(float x) {
     const __bf16 b = (__bf16)x;            // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
@@ -55,92 +52,135 @@ __global__ void k_planes_bf16(const BgState* __restrict__ states, uint32_t n, ui
 // MODE 1: out = relu(conv + bias + res)    (ResBlock conv2 + skip;      nnet.rs:29-33)
 // MODE 2: heads: channels 0..31 -> policy features bf16 [g][p*32+c], 32..34 -> value features f32
 //         [g][p*3+c], both after ReLU       (nnet.rs:75-79, 87-91)
-template <int C_IN, int MODE>
-__global__ __launch_bounds__(256) void k_conv3x3(const uint16_t* __restrict__ act,      // [M][C_IN] bf16
-                                                 const u32x4* __restrict__ wpack,      // [N/32][KSTEPS][64] x 16 B
-                                                 const float* __restrict__ bias,       // [N]
-                                                 const uint16_t* __restrict__ res,     // [M][N] bf16 (MODE 1)
-                                                 uint16_t* __restrict__ out,           // [M][N] bf16 / policy feats
-                                                 float* __restrict__ out_v,            // value feats (MODE 2)
-                                                 int M, int N) {
+// GT = boards per workgroup (rows = 24*GT, padded to MF fragments of 32), NW = waves (32 channels each).
+template <int C_IN, int MODE, int GT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict__ act,      // [M][C_IN] bf16
+                                                     const u32x4* __restrict__ wpack,      // [N/32][KSTEPS][64] x 16 B
+                                                     const float* __restrict__ bias,       // [N]
+                                                     const uint16_t* __restrict__ res,     // [M][N] bf16 (MODE 1)
+                                                     uint16_t* __restrict__ out,           // [M][N] bf16 / policy feats
+                                                     float* __restrict__ out_v,            // value feats (MODE 2)
+                                                     int M, int N) {
+    constexpr int ROWS = GT * 24;
+    constexpr int MF = (ROWS + 31) / 32;
+    constexpr int NT = 64 * NW;
     constexpr int RS = C_IN * 2 + 16;              // LDS row stride (bytes): +16 B pad => conflict-free b128
     constexpr int CPR = C_IN * 2 / 16;             // 16-B chunks per row
     constexpr int CSTEPS = C_IN / 16;              // channel steps of 16
     constexpr int KSTEPS = CSTEPS * 9;
+    constexpr int UNR = CSTEPS >= 2 ? 2 : 1;       // channel steps per loop body (18 / 9 MFMA k-steps)
+    constexpr int ORS = NW * 32 * 4 + 16;          // epilogue tile row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRows;
-    const int nslice = blockIdx.y * 4 + wave;      // 32 output channels per wave
+    const int row0 = blockIdx.x * ROWS;
+    const int nslice = blockIdx.y * NW + wave;     // 32 output channels per wave
 
-    // ---- stage the activation tile (whole boards, all input channels) ----
-    for (int i = tid; i < kRows * CPR; i += 256) {
-        const int r = i / CPR, ch = i % CPR;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
-        *(u32x4*)(smem + r * RS + ch * 16) = v;
-    }
-    if (tid < CPR + 1) *(u32x4*)(smem + kRows * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};   // zero row
-    // per-lane LDS byte addresses of the A fragments: [tap][M-fragment]
-    int base[9][kMFrags];
-#pragma unroll
-    for (int f = 0; f < kMFrags; ++f) {
-        const int R = 32 * f + (lane & 31);
-        const int p = R % 24, y = p / 6, x = p % 6;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool ok = (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
-            const int src = ok ? R + 6 * dy + dx : kRows;
-            base[t][f] = src * RS + (lane >> 5) * 16;
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc[kMFrags];
-#pragma unroll
-    for (int f = 0; f < kMFrags; ++f)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
-
+    // weights: issue the first 9 fragment loads before touching the activation tile
     const u32x4* wp = wpack + (size_t)nslice * KSTEPS * 64 + lane;
     u32x4 bq[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) bq[t] = wp[t * 64];
 
-    for (int cs = 0; cs < CSTEPS; ++cs) {
-        const int nxt = (cs + 1 < CSTEPS ? cs + 1 : cs) * 9;
+    // ---- stage the activation tile (whole boards, all input channels) ----
+    for (int i = tid; i < ROWS * CPR; i += NT) {
+        const int r = i / CPR, ch = i % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
+        *(u32x4*)(smem + r * RS + ch * 16) = v;
+    }
+    for (int i = tid; i < CPR + 3; i += NT) *(u32x4*)(smem + ROWS * RS + i * 16) = u32x4{0u, 0u, 0u, 0u};   // zero row
+    // per-lane LDS byte addresses of the A fragments: [tap][M-fragment]
+    int base[9][MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int R = 32 * f + (lane & 31);
+        const int p = R % 24, y = p / 6, x = p % 6;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[t]);
-            bq[t] = wp[(nxt + t) * 64];                       // prefetch the same tap of the next channel step
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            const int src = ok ? R + 6 * dy + dx : ROWS;
+            base[t][f] = src * RS + (lane >> 5) * 16;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[MF];
 #pragma unroll
-            for (int f = 0; f < kMFrags; ++f) {
-                const bf16x8 a = *(const bf16x8*)(smem + base[t][f] + cs * 32);
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[f], 0, 0, 0);
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+
+    // software pipeline: A fragments of k-step s+1 are read from LDS while the MFMAs of k-step s
+    // issue; the weight fragment of k-step s+9 is requested from L2 at k-step s.
+    bf16x8 a[2][MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
+    for (int it = 0; it < CSTEPS / UNR; ++it) {
+#pragma unroll
+        for (int u = 0; u < 9 * UNR; ++u) {
+            const int t = u % 9, cur = u & 1, nxt = cur ^ 1;
+            const int un = u + 1;                                  // next k-step inside / after this body
+            const int tn = un % 9;
+            const int csn = it * UNR + un / 9;                     // may be CSTEPS on the very last step: reads padding, unused
+#pragma unroll
+            for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[tn][f] + csn * 32);
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[t]);
+            {
+                const int cs_pf = it * UNR + u / 9 + 1;            // same tap, next channel step
+                bq[t] = wp[((cs_pf < CSTEPS ? cs_pf : CSTEPS - 1) * 9 + t) * 64];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
-    const int n = nslice * 32 + (lane & 31);
-    const float bv = bias[n];
+    // ---- epilogue: accumulators -> LDS tile [ROWS][NW*32] f32 -> 16-byte coalesced global stores ----
+    __syncthreads();                               // every wave is done reading the activation tile
+    {
+        const float bv = bias[nslice * 32 + (lane & 31)];
 #pragma unroll
-    for (int f = 0; f < kMFrags; ++f) {
+        for (int f = 0; f < MF; ++f)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = row0 + 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            if (r >= M) continue;
-            float v = acc[f][i] + bv;
-            if (MODE == 1) v += bf2f(res[(size_t)r * N + n]);
-            v = v > 0.0f ? v : 0.0f;
-            if (MODE == 2) {
-                const int g = r / 24, p = r % 24;
-                if (n < 32) out[(size_t)g * 768 + p * 32 + n] = f2bf(v);
-                else if (n < 35) out_v[(size_t)g * 72 + p * 3 + (n - 32)] = v;
-            } else {
-                out[(size_t)r * N + n] = f2bf(v);
+            for (int i = 0; i < 16; ++i) {         // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+                const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (r < ROWS) *(float*)(smem + r * ORS + (wave * 32 + (lane & 31)) * 4) = acc[f][i] + bv;
             }
+    }
+    __syncthreads();
+    constexpr int CHUNKS = ROWS * NW * 4;          // 8-channel chunks
+    const int nbase = blockIdx.y * NW * 32;
+    for (int i = tid; i < CHUNKS; i += NT) {
+        const int r = i / (NW * 4), c8 = i % (NW * 4);
+        const int gr = row0 + r;
+        if (gr >= M) continue;
+        const float4 lo = *(const float4*)(smem + r * ORS + c8 * 32);
+        const float4 hi = *(const float4*)(smem + r * ORS + c8 * 32 + 16);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (MODE == 1) {
+            const u32x4 rv = *(const u32x4*)(res + (size_t)gr * N + nbase + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] += __uint_as_float(rv[j] << 16);
+                v[2 * j + 1] += __uint_as_float(rv[j] & 0xffff0000u);
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = v[2 * j] > 0.0f ? v[2 * j] : 0.0f, x1 = v[2 * j + 1] > 0.0f ? v[2 * j + 1] : 0.0f;
+            o[j] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
+            v[2 * j] = x0; v[2 * j + 1] = x1;
+        }
+        if (MODE == 2) {
+            const int g = gr / 24, p = gr % 24, n0 = nbase + c8 * 8;
+            if (n0 < 32) *(u32x4*)(out + (size_t)g * 768 + p * 32 + n0) = o;
+            else if (n0 == 32) { float* ov = out_v + (size_t)g * 72 + p * 3; ov[0] = v[0]; ov[1] = v[1]; ov[2] = v[2]; }
+        } else {
+            *(u32x4*)(out + (size_t)gr * N + nbase + c8 * 8) = o;
         }
     }
 }
@@ -217,35 +257,66 @@ __global__ __launch_bounds__(64) void k_softmax_value(const float* __restrict__ 
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
-static int lds_bytes(int c_in) { return (kRows + 1) * (c_in * 2 + 16) + 16 * 2; }
-
-void nn_setup_kernels() {
-    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
-    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
-    (void)hipFuncSetAttribute((const void*)k_conv3x3<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256));
-    (void)hipFuncSetAttribute((const void*)k_conv3x3<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(16));
+template <int C_IN, int GT>
+static constexpr int conv_lds_bytes() {
+    constexpr int rows = GT * 24;
+    constexpr int a = (rows + 1) * (C_IN * 2 + 16) + 16 * 34 + 64;     // tile + zero row + over-read slack
+    constexpr int o = rows * (4 * 32 * 4 + 16);
+    return a > o ? a : o;
 }
+
+template <int C_IN, int MODE, int GT, int NW>
+static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
+                        uint16_t* out, float* out_v, int G, int N) {
+    static bool attr_set = false;
+    constexpr int lds = conv_lds_bytes<C_IN, GT>();
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const dim3 grid((G + GT - 1) / GT, N / (32 * NW)), block(64 * NW);
+    hipLaunchKernelGGL((k_conv3x3<C_IN, MODE, GT, NW>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out,
+                       out_v, G * 24, N);
+}
+
+void nn_setup_kernels() {}
 
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out) {
     if (!n) return;
     hipLaunchKernelGGL(k_planes_bf16, dim3((n * 24 + 255) / 256), dim3(256), 0, st, (const BgState*)states, n, out);
 }
 
+static int g_conv_variant = -1;     // development override (diee_dev_set_conv_variant): 0 auto, 1..4 fixed
+void nn_set_conv_variant(int v) { g_conv_variant = v; }
+
+// geometry by batch size: keep ~>=256 workgroups in flight while boards per workgroup (weight reuse) stay high
+static int pick_variant(int G) {
+    if (g_conv_variant > 0) return g_conv_variant;
+    if (G > 512) return 1;          // 8 boards x 128 channels, 4 waves
+    if (G > 256) return 2;          // 4 boards x 128 channels, 4 waves
+    if (G > 64) return 3;           // 2 boards x 64 channels,  2 waves
+    return 4;                       // 2 boards x 32 channels,  1 wave
+}
+
+template <int MODE>
+static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias,
+                             const uint16_t* res, uint16_t* out, float* out_v, int G, int N) {
+    switch (pick_variant(G)) {
+        case 1: conv_launch<256, MODE, 8, 4>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 2: conv_launch<256, MODE, 4, 4>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 3: conv_launch<256, MODE, 2, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        default: conv_launch<256, MODE, 2, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
+    }
+}
+
 // mode: 0 relu(conv+b), 1 relu(conv+b+res), 2 heads; c_in 16 (init block, 6 real channels) or 256
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
                     const uint16_t* res, uint16_t* out, float* out_v, int G, int N) {
     if (G <= 0) return;
-    const dim3 grid((G + kGames - 1) / kGames, N / 128), block(256);
-    const int M = G * 24;
-    const size_t lds = (size_t)lds_bytes(c_in);
-    if (c_in == 16)
-        hipLaunchKernelGGL((k_conv3x3<16, 0>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
-    else if (mode == 0)
-        hipLaunchKernelGGL((k_conv3x3<256, 0>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
-    else if (mode == 1)
-        hipLaunchKernelGGL((k_conv3x3<256, 1>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
-    else
-        hipLaunchKernelGGL((k_conv3x3<256, 2>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out, out_v, M, N);
+    if (c_in == 16) conv_launch<16, 0, 8, 4>(st, act, wpack, bias, res, out, out_v, G, N);
+    else if (mode == 0) conv256_dispatch<0>(st, act, wpack, bias, res, out, out_v, G, N);
+    else if (mode == 1) conv256_dispatch<1>(st, act, wpack, bias, res, out, out_v, G, N);
+    else conv_launch<256, 2, 4, 2>(st, act, wpack, bias, res, out, out_v, G, N);     // heads: N = 64 (35 real)
 }
 
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G) {

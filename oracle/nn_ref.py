@@ -1,5 +1,5 @@
 """PyTorch fp32 restatement of the reference's ResNet (src/alphazero/nnet.rs:24-34,57-133) built from
-the flat weight blob of include/diee.h.  Test infrastructure: the fp32 reference the bf16 MFMA
+the flat weight blob of include/diee.h.  TEST INFRASTRUCTURE (part of the oracle): the fp32 reference the bf16 MFMA
 kernels are compared against (the reference pins no network outputs: SURVEY section 4)."""
 import numpy as np
 import torch
