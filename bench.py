@@ -69,9 +69,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import importlib
+    ddist = importlib.import_module("die-e_amd.dist")
+    rank, local_rank, world = ddist.rank_world()
     dist = None
     if world > 1:
         import torch
@@ -83,7 +83,7 @@ def main():
     eng = diee_amd.Engine(local_rank)              # raises without a GPU: there is no CPU path
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
-    first_id = rank * args.games
+    first_id = ddist.shard_first_game_id(rank, args.games)
     # primer (not a step): pages in the code objects and sizes the HBM arenas
     eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=False)
 
@@ -112,13 +112,8 @@ def main():
     keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "fragments", "illegal_decodes"]
     if dist is not None:
-        import torch
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        vec = torch.tensor([float(tot[k]) for k in keys], dtype=torch.float64, device="cuda")
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        tot.update({k: float(v) for k, v in zip(keys, vec.tolist())})
+        dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
+        tot.update(red)
 
     if rank == 0:
         games = tot["games"]

@@ -1,0 +1,84 @@
+"""CPU checks of the drop-in boundary: libdiee.so loads, exports every symbol include/diee.h declares,
+and fails loudly (no CPU fallback) when no GPU is present.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import diee_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "diee.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(diee_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(diee_amd.LIB_PATH):
+        import importlib
+        importlib.import_module("die-e_amd.build").build()
+    L = diee_amd.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(L, s), f"{s} is declared in include/diee.h but not exported by libdiee.so"
+    assert sorted(diee_amd.EXPORTS) == syms, "die-e_amd.EXPORTS is out of sync with include/diee.h"
+    assert b"gfx950" in L.diee_version()
+
+
+def test_state_struct_is_32_bytes_and_matches_the_oracle(oracle):
+    assert diee_amd.BG_STATE.itemsize == 32 == oracle.BG_STATE.itemsize
+    assert diee_amd.BG_STATE.fields.keys() == oracle.BG_STATE.fields.keys()
+    for k in diee_amd.BG_STATE.fields:
+        assert diee_amd.BG_STATE.fields[k][1] == oracle.BG_STATE.fields[k][1]
+
+
+def test_no_gpu_means_loud_failure_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(diee_amd.DieeError) as ei:
+        diee_amd.Engine(0)
+    assert ei.value.status == diee_amd.ERR_HIP
+    # unsupported game id / bad args are status codes, never aborts
+    L = diee_amd.load_library()
+    h = C.c_void_p()
+    assert L.diee_create(0, diee_amd.GAME_TTT, C.byref(h)) == diee_amd.ERR_UNSUPPORTED
+    assert L.diee_create(0, 1, None) == diee_amd.ERR_ARG
+    assert L.diee_load_weights(None, None, 0) == diee_amd.ERR_ARG
+
+
+def test_weight_blob_layout_and_random_init_on_host():
+    n = diee_amd.weights_count()
+    # init 6->256, 19 blocks of two 256->256 convs, heads (~23.58 M parameters + BN stats)
+    conv = lambda co, ci: co * ci * 9 + co
+    expect = (conv(256, 6) + 4 * 256 + 19 * (2 * conv(256, 256) + 8 * 256)
+              + conv(32, 256) + 4 * 32 + 1352 * 768 + 1352 + conv(3, 256) + 12 + 72 + 1)
+    assert n == expect
+    a = diee_amd.random_weights(0); b = diee_amd.random_weights(0); c = diee_amd.random_weights(1)
+    assert a.size == n and (a == b).all() and (a != c).any() and np.isfinite(a).all()
+    # tch defaults: conv weights U(+-1/sqrt(fan_in)), conv bias 0, BN gamma U(0,1) beta 0 mean 0 var 1
+    w0 = a[:256 * 6 * 9]
+    bd = 1 / np.sqrt(54)
+    assert abs(w0).max() <= bd and abs(w0).max() > 0.9 * bd and abs(w0.mean()) < 0.01
+    assert (a[256 * 6 * 9:256 * 6 * 9 + 256] == 0).all()
+    g = a[256 * 6 * 9 + 256:256 * 6 * 9 + 512]
+    assert g.min() >= 0 and g.max() <= 1 and 0.4 < g.mean() < 0.6
+    assert diee_amd.load_library().diee_random_weights(1, 0, a.ctypes.data, n - 1) == diee_amd.ERR_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "die-e_amd")
+    for dp, _, files in os.walk(pkg):
+        if os.sep + "build" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "diee_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the N>1 path of bench.py: block-partitioned game ids, no data-path
+collective, barrier + MAX(time) / SUM(counters) reduction.  Each rank plays its shard with the CPU
+oracle (the stand-in for the GPU engine on this box); the union must equal the unsharded batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import importlib
+    import time
+    import torch.distributed as dist
+    ddist = importlib.import_module("die-e_amd.dist")
+    from oracle import oracle as orc
+    r, lr, w = ddist.rank_world()
+    assert (r, w) == (rank, world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    games = 3
+    first = ddist.shard_first_game_id(r, games)
+    cfg = orc.MctsCfg(iterations=6, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    dist.barrier()
+    t0 = time.perf_counter()
+    out = orc.self_play_parallel(1, games, cfg, 1.25, 11, orc.hash_eval_fn(), orc.game(1), ref_quirks=0, first_game_id=first)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tot = {"games": games, "expansions": out["stats"]["expansions"], "plies": int(out["plies"].sum())}
+    tmax, red = ddist.reduce_stats(dist, dt, tot, ["games", "expansions", "plies"], "cpu")
+    q.put((rank, dt, tmax, red, out["game"].tolist(), out["ps"].tobytes(), out["stats"]["expansions"]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_self_play_gloo(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, dt0, tmax0, red0, games0, ps0, e0), (r1, dt1, tmax1, red1, games1, ps1, e1) = res
+    assert tmax0 == tmax1 == max(dt0, dt1)                        # MAX over ranks
+    assert red0 == red1 and red0["games"] == 6 and red0["expansions"] == e0 + e1
+    assert set(games0) == {0, 1, 2} and set(games1) == {3, 4, 5}  # block partition of the ids
+    cfg = oracle.MctsCfg(iterations=6, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    full = oracle.self_play_parallel(1, 6, cfg, 1.25, 11, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=0)
+    a = np.frombuffer(ps0, dtype=np.float32).reshape(-1, 1352); b = np.frombuffer(ps1, dtype=np.float32).reshape(-1, 1352)
+    for g in range(6):
+        part, gl = (a, np.array(games0)) if g < 3 else (b, np.array(games1))
+        assert part[gl == g].tobytes() == full["ps"][full["game"] == g].tobytes()
