@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=100)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
     args = ap.parse_args()
 
     import importlib
@@ -95,7 +96,7 @@ def main():
 
     def run_step(i):
         return eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
-                                      first_game_id=first_id, fetch=False)["stats"]
+                                      first_game_id=first_id, fetch=False, max_steps=args.max_steps)["stats"]
 
     for i in range(args.warmup):
         run_step(1000 + i)
@@ -126,7 +127,7 @@ def main():
             "config": {"workload": f"backgammon self_play_parallel, num_self_play_batches={args.games} per GPU, "
                                    f"iterations={args.iterations}, exploration_const=2, temperature=1.25, "
                                    "simulate_round_limit=400, dirichlet 0.3/0.25, random-init 19x256 ResNet (seed 0), "
-                                   "ref_quirks on", "parallelism": f"dp{world} (independent games, no collective)"},
+                                   "ref_quirks on" + (f", TRUNCATED to {args.max_steps} move-steps per batch (profiling run)" if args.max_steps else ""), "parallelism": f"dp{world} (independent games, no collective)"},
             "node_expansions_per_s": tot["expansions"] / dt,
             "nn_evals_per_s": tot["nn_evals"] / dt,
             "mfma_fraction_end_to_end": tot["nn_evals"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world),

@@ -185,19 +185,18 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
     launch_planes_bf16(st, states_dev, (uint32_t)G, W.x16.p);
     launch_conv3x3(st, 16, 0, W.x16.p, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+    // sampled timing of the 38-launch tower chain: one HIP-event pair per sampled forward (per-launch
+    // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
     for (int i = 0; i < BLOCKS; ++i) {
-        for (int half = 0; half < 2; ++half) {
-            hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
-            if (half == 0)
-                launch_conv3x3(st, 256, 0, W.actX.p, W.wconv[1 + 2 * i].p, W.bconv[1 + 2 * i].p, nullptr, W.actH.p, nullptr, G, 256);
-            else    // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
-                launch_conv3x3(st, 256, 1, W.actH.p, W.wconv[2 + 2 * i].p, W.bconv[2 + 2 * i].p, W.actX.p, W.actX.p, nullptr, G, 256);
-            if (sample) {
-                HIPCHK(hipEventRecord(ev1, st));
-                W.pending.push_back({ev0, ev1, 2.0 * G * 24.0 * 2304.0 * 256.0});
-            }
-        }
+        launch_conv3x3(st, 256, 0, W.actX.p, W.wconv[1 + 2 * i].p, W.bconv[1 + 2 * i].p, nullptr, W.actH.p, nullptr, G, 256);
+        // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
+        launch_conv3x3(st, 256, 1, W.actH.p, W.wconv[2 + 2 * i].p, W.bconv[2 + 2 * i].p, W.actX.p, W.actX.p, nullptr, G, 256);
+    }
+    if (sample) {
+        HIPCHK(hipEventRecord(ev1, st));
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, 38});
     }
     launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
@@ -212,7 +211,7 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     for (auto& p : W.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            W.conv_seconds += ms * 1e-3; W.conv_launches += 1; W.conv_flops += p.flops;
+            W.conv_seconds += ms * 1e-3; W.conv_launches += p.launches; W.conv_flops += p.flops;
         }
         W.free_events.push_back(p.a); W.free_events.push_back(p.b);
     }

@@ -17,10 +17,10 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; };
+    struct Pending { hipEvent_t a, b; double flops; int launches; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
-    int sample_every = 61;
+    int sample_every = 17;
     uint64_t forward_count = 0;
     double conv_seconds = 0, conv_flops = 0;
     uint64_t conv_launches = 0;

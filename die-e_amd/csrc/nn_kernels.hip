@@ -185,6 +185,118 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     }
 }
 
+// Small-batch variant of the tower conv: when few games are alive the layer is latency-bound, so the
+// K dimension (16 channel steps) is split over the 4 waves of a workgroup (split-K inside the
+// workgroup, partial tiles reduced through LDS) and a workgroup owns only GT boards x 32 channels:
+// 8x more workgroups than the large-batch geometry, 36 instead of 144 dependent k-steps per wave,
+// and each wave requests its whole 36 KiB weight stream up front.
+template <int MODE, int GT>
+__global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__ act,       // [M][256] bf16
+                                                    const u32x4* __restrict__ wpack,       // [N/32][144][64] x 16 B
+                                                    const float* __restrict__ bias,
+                                                    const uint16_t* __restrict__ res,
+                                                    uint16_t* __restrict__ out, int M, int N) {
+    constexpr int C_IN = 256, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = C_IN * 2 + 16, CPR = 32;
+    constexpr int KS = 36;                          // k-steps per wave: 4 channel steps x 9 taps
+    constexpr int PF = GT <= 2 ? 36 : 18;           // weight fragments in flight per wave
+    constexpr int PRS = 32 * 4 + 16;                // partial-tile row stride (bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* part = smem;                              // [4 waves][MF*32 rows][32] f32, aliases the activation tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS;
+    const int nslice = blockIdx.y;
+
+    const u32x4* wp = wpack + ((size_t)nslice * 144 + wave * KS) * 64 + lane;
+    u32x4 bq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) bq[i] = wp[i * 64];
+
+    for (int i = tid; i < ROWS * CPR; i += 256) {
+        const int r = i / CPR, ch = i % CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
+        *(u32x4*)(smem + r * RS + ch * 16) = v;
+    }
+    for (int i = tid; i < CPR + 3; i += 256) *(u32x4*)(smem + ROWS * RS + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    int base[9][MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int R = 32 * f + (lane & 31);
+        const int p = R % 24, y = p / 6, x = p % 6;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            const int src = ok ? R + 6 * dy + dx : ROWS;
+            base[t][f] = src * RS + (lane >> 5) * 16 + wave * 4 * 32;     // this wave's channel quarter
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+    bf16x8 a[2][MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        const int t = u % 9, cur = u & 1, nxt = cur ^ 1, un = u + 1;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+        const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
+        if (u + PF < KS) bq[u % PF] = wp[(u + PF) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        (void)t;
+    }
+
+    // partial tiles -> LDS, then all 256 threads reduce the 4 partials and run the epilogue
+    __syncthreads();                                // every wave is done reading the activation tile
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            *(float*)(part + ((wave * MF * 32 + r) * PRS) + (lane & 31) * 4) = acc[f][i];
+        }
+    __syncthreads();
+    for (int i = tid; i < ROWS * 4; i += 256) {
+        const int r = i >> 2, c8 = i & 3;
+        const int gr = row0 + r;
+        if (gr >= M) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bias[nslice * 32 + c8 * 8 + j];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float4 lo = *(const float4*)(part + (w * MF * 32 + r) * PRS + c8 * 32);
+            const float4 hi = *(const float4*)(part + (w * MF * 32 + r) * PRS + c8 * 32 + 16);
+            v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+        }
+        if (MODE == 1) {
+            const u32x4 rv = *(const u32x4*)(res + (size_t)gr * N + nslice * 32 + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] += __uint_as_float(rv[j] << 16);
+                v[2 * j + 1] += __uint_as_float(rv[j] & 0xffff0000u);
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = v[2 * j] > 0.0f ? v[2 * j] : 0.0f, x1 = v[2 * j + 1] > 0.0f ? v[2 * j + 1] : 0.0f;
+            o[j] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
+        }
+        *(u32x4*)(out + (size_t)gr * N + nslice * 32 + c8 * 8) = o;
+    }
+}
+
 // policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight
 // from L2 (the layer is ~0.2 % of the network's FLOPs).
 __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
@@ -279,6 +391,21 @@ static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, 
                        out_v, G * 24, N);
 }
 
+template <int MODE, int GT>
+static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
+                           uint16_t* out, int G, int N) {
+    static bool attr_set = false;
+    constexpr int rows = GT * 24, mf = (rows + 31) / 32;
+    constexpr int lds_a = (rows + 1) * 528 + 16 * 34 + 64, lds_p = 4 * mf * 32 * (32 * 4 + 16);
+    constexpr int lds = lds_a > lds_p ? lds_a : lds_p;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_conv3x3_sk<MODE, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT>), dim3((G + GT - 1) / GT, N / 32), dim3(256), lds, st, act,
+                       (const u32x4*)wpack, bias, res, out, G * 24, N);
+}
+
 void nn_setup_kernels() {}
 
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out) {
@@ -286,16 +413,18 @@ void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t
     hipLaunchKernelGGL(k_planes_bf16, dim3((n * 24 + 255) / 256), dim3(256), 0, st, (const BgState*)states, n, out);
 }
 
-static int g_conv_variant = -1;     // development override (diee_dev_set_conv_variant): 0 auto, 1..4 fixed
+static int g_conv_variant = -1;     // development override (diee_dev_conv_bench): <= 0 auto, 1..7 fixed
 void nn_set_conv_variant(int v) { g_conv_variant = v; }
 
 // geometry by batch size: keep ~>=256 workgroups in flight while boards per workgroup (weight reuse) stay high
 static int pick_variant(int G) {
     if (g_conv_variant > 0) return g_conv_variant;
-    if (G > 512) return 1;          // 8 boards x 128 channels, 4 waves
-    if (G > 256) return 2;          // 4 boards x 128 channels, 4 waves
-    if (G > 64) return 3;           // 2 boards x 64 channels,  2 waves
-    return 4;                       // 2 boards x 32 channels,  1 wave
+    // measured (scripts/conv_sweep.py, MI355X, us per launch): large batches are throughput-bound and want
+    // 4 boards x 128 channels per workgroup (up to 3 workgroups per CU); small batches are latency-bound
+    // and want the split-K geometry (8x more workgroups, 4x shorter dependent chains)
+    if (G > 320) return 2;          // 4 boards x 128 channels, 4 waves
+    if (G > 80) return 6;           // split-K, 4 boards x 32 channels
+    return 5;                       // split-K, 2 boards x 32 channels
 }
 
 template <int MODE>
@@ -305,7 +434,10 @@ static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wp
         case 1: conv_launch<256, MODE, 8, 4>(st, act, wpack, bias, res, out, out_v, G, N); break;
         case 2: conv_launch<256, MODE, 4, 4>(st, act, wpack, bias, res, out, out_v, G, N); break;
         case 3: conv_launch<256, MODE, 2, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
-        default: conv_launch<256, MODE, 2, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 4: conv_launch<256, MODE, 2, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 5: conv_sk_launch<MODE, 2>(st, act, wpack, bias, res, out, G, N); break;
+        case 6: conv_sk_launch<MODE, 4>(st, act, wpack, bias, res, out, G, N); break;
+        default: conv_sk_launch<MODE, 8>(st, act, wpack, bias, res, out, G, N); break;
     }
 }
 
