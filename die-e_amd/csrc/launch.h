@@ -31,6 +31,7 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks);
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P);
+void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n);
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits);
 void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed);
 void launch_gather_roots(hipStream_t st, const Games& G, const Slots& S, uint32_t n_live, uint32_t first_id);

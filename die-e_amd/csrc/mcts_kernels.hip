@@ -53,6 +53,8 @@ __global__ void k_init_roots(Tree T, Slots S, uint32_t n) {
     T.parent[base] = kNone; T.first_child[base] = 0; T.meta[base] = 0xFFFFu;
     T.used[slot] = 1;
     S.sel[slot] = kNone; S.sel_value[slot] = 0.0f; S.leaf[slot] = 0; S.leaf_term[slot] = 0;
+#pragma unroll
+    for (int c = 0; c < SC_COUNT; ++c) S.slot_cnt[slot * SC_COUNT + c] = 0;
 }
 
 // ---- selection ---------------------------------------------------------------------------------
@@ -124,18 +126,18 @@ __global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint
     const BgState st = load_state(&T.state[base + node]);
     const int w = bg_winner_dev(st);
     if (lane == 0) {
-        atomicAdd(&S.counters[CNT_SELECTIONS], 1ull);
-        atomicAdd(&S.counters[CNT_DEPTH_SUM], (unsigned long long)depth);
+        uint32_t* sc = S.slot_cnt + slot * SC_COUNT;
+        sc[SC_SELECTIONS] += 1; sc[SC_DEPTH_SUM] += depth;
         if (w != 0) {                                       // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
             const BgState rs = load_state(&T.state[base]);
             const float v = w == st_player(rs) ? 1.0f : -1.0f;
             backprop(T, base, node, v);
             S.leaf_term[slot] = 1;
-            atomicAdd(&S.counters[CNT_TERMINAL], 1ull);
+            sc[SC_TERMINAL] += 1;
             if (quirks && S.sel[slot] == kNone) atomicAdd(&S.iter_flags[2 * it + 1], 1u);
         } else {
             S.leaf_term[slot] = 0; S.leaf[slot] = node; S.sel[slot] = node;
-            atomicOr(&S.iter_flags[2 * it], 1u);
+            S.iter_flags[2 * it] = 1u;                      // idempotent plain store (no same-address atomic storm)
             store_state(&S.eval_states[slot], st);
         }
     }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             if (root) {                                      // apply_dirichlet: (1-eps)*P + eps*noise
                 const float x = om * p, y = P.dir_eps * S.noise[code];
                 p = x + y;
-                if (bg_decode_dev(r0, r1, player, code) != play) atomicAdd(&S.counters[CNT_ILLEGAL], 1ull);
+                if (bg_decode_dev(r0, r1, player, code) != play) atomicAdd(&S.slot_cnt[slot * SC_COUNT + SC_ILLEGAL], 1u);
             }
             sc.raw[j] = p; sc.code[j] = (uint16_t)code;
         }
@@ -229,9 +231,9 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
                 T.first_child[base + node] = first;
                 T.meta[base + node] = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
                 T.used[slot] = first + (uint32_t)k;
-                atomicAdd(&S.counters[CNT_EXPANSIONS], 1ull);
-                atomicAdd(&S.counters[CNT_CHILDREN], (unsigned long long)k);
-                atomicMax(&S.counters[CNT_MAX_CHILDREN], (unsigned long long)k);
+                uint32_t* scn = S.slot_cnt + slot * SC_COUNT;
+                scn[SC_EXPANSIONS] += 1; scn[SC_CHILDREN] += (uint32_t)k;
+                if ((uint32_t)k > scn[SC_MAX_CHILDREN]) scn[SC_MAX_CHILDREN] = (uint32_t)k;
             }
         }
     }
@@ -244,6 +246,40 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             const uint32_t cnt = S.iter_flags[2 * it + 1];
             const float rv = S.root_value0[0];
             for (uint32_t i = 0; i < cnt; ++i) { T.visits[base] += 1.0f; T.value[base] += rv; }
+        }
+    }
+}
+
+// fold the per-slot counters of one move-step into the call totals (one block)
+__global__ __launch_bounds__(256) void k_reduce_counters(Slots S, uint32_t n) {
+    __shared__ unsigned long long part[SC_COUNT][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long acc[SC_COUNT];
+#pragma unroll
+    for (int c = 0; c < SC_COUNT; ++c) acc[c] = 0;
+    for (uint32_t s = tid; s < n; s += 256)
+#pragma unroll
+        for (int c = 0; c < SC_COUNT; ++c) {
+            const unsigned long long v = S.slot_cnt[s * SC_COUNT + c];
+            if (c == SC_MAX_CHILDREN) acc[c] = v > acc[c] ? v : acc[c]; else acc[c] += v;
+        }
+#pragma unroll
+    for (int c = 0; c < SC_COUNT; ++c) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(acc[c], d);
+            if (c == SC_MAX_CHILDREN) acc[c] = o > acc[c] ? o : acc[c]; else acc[c] += o;
+        }
+        if (lane == 0) part[c][wave] = acc[c];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int map[SC_COUNT] = {CNT_SELECTIONS, CNT_DEPTH_SUM, CNT_TERMINAL, CNT_EXPANSIONS, CNT_CHILDREN, CNT_MAX_CHILDREN, CNT_ILLEGAL};
+        for (int c = 0; c < SC_COUNT; ++c) {
+            unsigned long long t = 0;
+            for (int w = 0; w < 4; ++w) t = c == SC_MAX_CHILDREN ? (part[c][w] > t ? part[c][w] : t) : t + part[c][w];
+            if (c == SC_MAX_CHILDREN) { if (t > S.counters[map[c]]) S.counters[map[c]] = t; }
+            else S.counters[map[c]] += t;
         }
     }
 }
@@ -430,6 +466,9 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, ui
 }
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P) {
     hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, n, it, P);
+}
+void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n) {
+    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(256), 0, st, S, n);
 }
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits) {
     hipLaunchKernelGGL(k_root_probs, dim3(n), dim3(64), 0, st, T, n, probs, nch, root_visits);

@@ -1,6 +1,7 @@
 // nn_host.cpp -- ResNet weights (blob layout of include/diee.h, BatchNorm folding, MFMA fragment
 // packing) and the forward pass driver.  Reference: src/alphazero/nnet.rs:57-133.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bg_device.h"
@@ -183,8 +184,8 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     nn_reserve(e, G);
     hipStream_t st = e.stream;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
-    launch_planes_bf16(st, states_dev, (uint32_t)G, W.x16.p);
-    launch_conv3x3(st, 16, 0, W.x16.p, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+    // the init block reads the states and builds the input planes itself (no separate planes kernel)
+    launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
     // sampled timing of the 38-launch tower chain: one HIP-event pair per sampled forward (per-launch
     // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -230,8 +231,9 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     nn_reserve(e, G);
     hipStream_t st = e.stream;
     const size_t M = (size_t)((G + 7) / 8 * 8) * 24;
-    HIPCHK(hipMemsetAsync(W.actX.p, 0x3c, M * 256 * 2, st));     // bf16 0x3c3c ~ 0.0115
-    HIPCHK(hipMemsetAsync(W.actH.p, 0x3c, M * 256 * 2, st));
+    const int fill = getenv("DIEE_BENCH_ZERO") ? 0 : 0x3c;
+    HIPCHK(hipMemsetAsync(W.actX.p, fill, M * 256 * 2, st));     // bf16 0x3c3c ~ 0.0115
+    HIPCHK(hipMemsetAsync(W.actH.p, fill, M * 256 * 2, st));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     nn_set_conv_variant(variant);

@@ -53,7 +53,7 @@ __global__ void k_planes_bf16(const BgState* __restrict__ states, uint32_t n, ui
 // MODE 2: heads: channels 0..31 -> policy features bf16 [g][p*32+c], 32..34 -> value features f32
 //         [g][p*3+c], both after ReLU       (nnet.rs:75-79, 87-91)
 // GT = boards per workgroup (rows = 24*GT, padded to MF fragments of 32), NW = waves (32 channels each).
-template <int C_IN, int MODE, int GT, int NW>
+template <int C_IN, int MODE, int GT, int NW, int PD = 1, int DBG = 0, int NF = 1>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict__ act,      // [M][C_IN] bf16
                                                      const u32x4* __restrict__ wpack,      // [N/32][KSTEPS][64] x 16 B
                                                      const float* __restrict__ bias,       // [N]
@@ -69,24 +69,41 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     constexpr int CSTEPS = C_IN / 16;              // channel steps of 16
     constexpr int KSTEPS = CSTEPS * 9;
     constexpr int UNR = CSTEPS >= 2 ? 2 : 1;       // channel steps per loop body (18 / 9 MFMA k-steps)
-    constexpr int ORS = NW * 32 * 4 + 16;          // epilogue tile row stride (bytes)
+    constexpr int NC = NW * NF * 32;               // output channels per workgroup
+    constexpr int ORS = NC * 4 + 16;               // epilogue tile row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
-    const int nslice = blockIdx.y * NW + wave;     // 32 output channels per wave
+    const int nslice = (blockIdx.y * NW + wave) * NF;   // NF x 32 output channels per wave
 
     // weights: issue the first 9 fragment loads before touching the activation tile
     const u32x4* wp = wpack + (size_t)nslice * KSTEPS * 64 + lane;
-    u32x4 bq[9];
+    u32x4 bq[9][NF];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) bq[t] = wp[t * 64];
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) bq[t][q] = wp[((size_t)q * KSTEPS + t) * 64];
 
     // ---- stage the activation tile (whole boards, all input channels) ----
     for (int i = tid; i < ROWS * CPR; i += NT) {
         const int r = i / CPR, ch = i % CPR;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
+        if (C_IN == 16) {
+            // init block: `act` is the BgState array; build the as_tensor planes (backgammon_logic.rs:198-252)
+            // on the fly as bf16 (6 real channels, small integers: exact)
+            if (row0 + r < M && ch == 0) {
+                const BgState st = *((const BgState*)act + (row0 + r) / 24);
+                const int p = (row0 + r) % 24;
+                uint32_t w[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    w[c] = (uint32_t)f2bf(bg_plane_dev(st, 2 * c, p)) | ((uint32_t)f2bf(bg_plane_dev(st, 2 * c + 1, p)) << 16);
+                v = u32x4{w[0], w[1], w[2], 0u};
+            }
+        } else if (row0 + r < M) {
+            v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
+        }
         *(u32x4*)(smem + r * RS + ch * 16) = v;
     }
     for (int i = tid; i < CPR + 3; i += NT) *(u32x4*)(smem + ROWS * RS + i * 16) = u32x4{0u, 0u, 0u, 0u};   // zero row
@@ -106,34 +123,49 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     }
     __syncthreads();
 
-    f32x16 acc[MF];
+    f32x16 acc[MF][NF];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
-
-    // software pipeline: A fragments of k-step s+1 are read from LDS while the MFMAs of k-step s
-    // issue; the weight fragment of k-step s+9 is requested from L2 at k-step s.
-    bf16x8 a[2][MF];
+        for (int q = 0; q < NF; ++q)
 #pragma unroll
-    for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
-    for (int it = 0; it < CSTEPS / UNR; ++it) {
+            for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.0f;
+
+    // software pipeline: A fragments of k-step s+PD are read from LDS while the MFMAs of k-step s
+    // issue (PD = 2 when a k-step has few MFMAs: LDS latency > 3 MFMAs); the weight fragment of
+    // k-step s+9 is requested from L2 at k-step s.
+    constexpr int NB = PD + 1;                     // A-fragment ring
+    static_assert(CSTEPS / UNR == 1 || (9 * UNR) % NB == 0, "ring index must be static");
+    bf16x8 a[NB][MF];
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int f = 0; f < MF; ++f) a[d][f] = *(const bf16x8*)(smem + base[d % 9][f] + (d / 9) * 32);
+    for (int it = 0; it < (DBG == 3 ? 0 : CSTEPS / UNR); ++it) {
 #pragma unroll
         for (int u = 0; u < 9 * UNR; ++u) {
-            const int t = u % 9, cur = u & 1, nxt = cur ^ 1;
-            const int un = u + 1;                                  // next k-step inside / after this body
+            const int t = u % 9, cur = u % NB, nxt = (u + PD) % NB;
+            const int un = u + PD;                                 // k-step to prefetch (inside / after this body)
             const int tn = un % 9;
-            const int csn = it * UNR + un / 9;                     // may be CSTEPS on the very last step: reads padding, unused
+            const int csn = it * UNR + un / 9;                     // may run past CSTEPS at the very end: reads padding, unused
+            if (DBG != 2)
 #pragma unroll
             for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[tn][f] + csn * 32);
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[t]);
-            {
+            bf16x8 b[NF];
+#pragma unroll
+            for (int q = 0; q < NF; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[t][q]);
+            if (DBG != 1) {
                 const int cs_pf = it * UNR + u / 9 + 1;            // same tap, next channel step
-                bq[t] = wp[((cs_pf < CSTEPS ? cs_pf : CSTEPS - 1) * 9 + t) * 64];
+#pragma unroll
+                for (int q = 0; q < NF; ++q)
+                    bq[t][q] = wp[((size_t)q * KSTEPS + (cs_pf < CSTEPS ? cs_pf : CSTEPS - 1) * 9 + t) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int q = 0; q < NF; ++q)
+                    acc[f][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b[q], acc[f][q], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -141,20 +173,24 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     // ---- epilogue: accumulators -> LDS tile [ROWS][NW*32] f32 -> 16-byte coalesced global stores ----
     __syncthreads();                               // every wave is done reading the activation tile
     {
-        const float bv = bias[nslice * 32 + (lane & 31)];
 #pragma unroll
-        for (int f = 0; f < MF; ++f)
+        for (int q = 0; q < NF; ++q) {
+            const float bv = bias[(nslice + q) * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {         // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-                const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (r < ROWS) *(float*)(smem + r * ORS + (wave * 32 + (lane & 31)) * 4) = acc[f][i] + bv;
-            }
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {     // C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+                    const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    if (r < ROWS) *(float*)(smem + r * ORS + ((wave * NF + q) * 32 + (lane & 31)) * 4) = acc[f][q][i] + bv;
+                }
+        }
     }
     __syncthreads();
-    constexpr int CHUNKS = ROWS * NW * 4;          // 8-channel chunks
-    const int nbase = blockIdx.y * NW * 32;
+    constexpr int CPRW = NC / 8;                   // 8-channel chunks per row
+    constexpr int CHUNKS = ROWS * CPRW;
+    const int nbase = blockIdx.y * NC;
     for (int i = tid; i < CHUNKS; i += NT) {
-        const int r = i / (NW * 4), c8 = i % (NW * 4);
+        const int r = i / CPRW, c8 = i % CPRW;
         const int gr = row0 + r;
         if (gr >= M) continue;
         const float4 lo = *(const float4*)(smem + r * ORS + c8 * 32);
@@ -195,7 +231,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
                                                     const u32x4* __restrict__ wpack,       // [N/32][144][64] x 16 B
                                                     const float* __restrict__ bias,
                                                     const uint16_t* __restrict__ res,
-                                                    uint16_t* __restrict__ out, int M, int N) {
+                                                    uint16_t* __restrict__ out, float* __restrict__ out_v,
+                                                    int M, int N) {
     constexpr int C_IN = 256, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = C_IN * 2 + 16, CPR = 32;
     constexpr int KS = 36;                          // k-steps per wave: 4 channel steps x 9 taps
     constexpr int PF = GT <= 2 ? 36 : 18;           // weight fragments in flight per wave
@@ -292,8 +329,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
         for (int j = 0; j < 4; ++j) {
             const float x0 = v[2 * j] > 0.0f ? v[2 * j] : 0.0f, x1 = v[2 * j + 1] > 0.0f ? v[2 * j + 1] : 0.0f;
             o[j] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
+            v[2 * j] = x0; v[2 * j + 1] = x1;
         }
-        *(u32x4*)(out + (size_t)gr * N + nslice * 32 + c8 * 8) = o;
+        if (MODE == 2) {                            // heads: slice 0 = policy features, slice 1 = value features
+            const int g = gr / 24, p = gr % 24;
+            if (nslice == 0) *(u32x4*)(out + (size_t)g * 768 + p * 32 + c8 * 8) = o;
+            else if (c8 == 0) { float* ov = out_v + (size_t)g * 72 + p * 3; ov[0] = v[0]; ov[1] = v[1]; ov[2] = v[2]; }
+        } else {
+            *(u32x4*)(out + (size_t)gr * N + nslice * 32 + c8 * 8) = o;
+        }
     }
 }
 
@@ -369,31 +413,31 @@ __global__ __launch_bounds__(64) void k_softmax_value(const float* __restrict__ 
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
-template <int C_IN, int GT>
+template <int C_IN, int GT, int NC>
 static constexpr int conv_lds_bytes() {
     constexpr int rows = GT * 24;
-    constexpr int a = (rows + 1) * (C_IN * 2 + 16) + 16 * 34 + 64;     // tile + zero row + over-read slack
-    constexpr int o = rows * (4 * 32 * 4 + 16);
+    constexpr int a = (rows + 1) * (C_IN * 2 + 16) + 16 * 34 + 128;    // tile + zero row + over-read slack
+    constexpr int o = rows * (NC * 4 + 16);
     return a > o ? a : o;
 }
 
-template <int C_IN, int MODE, int GT, int NW>
+template <int C_IN, int MODE, int GT, int NW, int PD = 1, int DBG = 0, int NF = 1>
 static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
                         uint16_t* out, float* out_v, int G, int N) {
     static bool attr_set = false;
-    constexpr int lds = conv_lds_bytes<C_IN, GT>();
+    constexpr int lds = conv_lds_bytes<C_IN, GT, NW * NF * 32>();
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW, PD, DBG, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const dim3 grid((G + GT - 1) / GT, N / (32 * NW)), block(64 * NW);
-    hipLaunchKernelGGL((k_conv3x3<C_IN, MODE, GT, NW>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out,
+    const dim3 grid((G + GT - 1) / GT, N / (32 * NW * NF)), block(64 * NW);
+    hipLaunchKernelGGL((k_conv3x3<C_IN, MODE, GT, NW, PD, DBG, NF>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out,
                        out_v, G * 24, N);
 }
 
 template <int MODE, int GT>
 static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
-                           uint16_t* out, int G, int N) {
+                           uint16_t* out, int G, int N, float* out_v = nullptr) {
     static bool attr_set = false;
     constexpr int rows = GT * 24, mf = (rows + 31) / 32;
     constexpr int lds_a = (rows + 1) * 528 + 16 * 34 + 64, lds_p = 4 * mf * 32 * (32 * 4 + 16);
@@ -403,7 +447,7 @@ static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpac
         attr_set = true;
     }
     hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT>), dim3((G + GT - 1) / GT, N / 32), dim3(256), lds, st, act,
-                       (const u32x4*)wpack, bias, res, out, G * 24, N);
+                       (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
 }
 
 void nn_setup_kernels() {}
@@ -437,6 +481,15 @@ static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wp
         case 4: conv_launch<256, MODE, 2, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
         case 5: conv_sk_launch<MODE, 2>(st, act, wpack, bias, res, out, G, N); break;
         case 6: conv_sk_launch<MODE, 4>(st, act, wpack, bias, res, out, G, N); break;
+        case 8: conv_launch<256, MODE, 4, 4, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 9: conv_launch<256, MODE, 4, 4, 1, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;   // timing only: no weight reloads
+        case 10: conv_launch<256, MODE, 4, 4, 1, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;  // timing only: no LDS reads
+        case 13: conv_launch<256, MODE, 4, 4, 1, 0, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;   // 4 boards x 256 ch, 2 N-frags per wave
+        case 14: conv_launch<256, MODE, 4, 2, 1, 0, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;   // 4 boards x 128 ch, 2 waves x 2 N-frags
+        case 15: conv_launch<256, MODE, 4, 4, 1, 3>(st, act, wpack, bias, res, out, out_v, G, N); break;      // timing only: no main loop
+        case 16: conv_launch<256, MODE, 4, 4, 1, 3, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 11: conv_launch<256, MODE, 8, 4, 1, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
+        case 12: conv_launch<256, MODE, 8, 4, 1, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
         default: conv_sk_launch<MODE, 8>(st, act, wpack, bias, res, out, G, N); break;
     }
 }
@@ -445,10 +498,14 @@ static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wp
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
                     const uint16_t* res, uint16_t* out, float* out_v, int G, int N) {
     if (G <= 0) return;
-    if (c_in == 16) conv_launch<16, 0, 8, 4>(st, act, wpack, bias, res, out, out_v, G, N);
+    if (c_in == 16) {
+        if (G > 512) conv_launch<16, 0, 8, 4>(st, act, wpack, bias, res, out, out_v, G, N);
+        else conv_launch<16, 0, 2, 2>(st, act, wpack, bias, res, out, out_v, G, N);
+    }
     else if (mode == 0) conv256_dispatch<0>(st, act, wpack, bias, res, out, out_v, G, N);
     else if (mode == 1) conv256_dispatch<1>(st, act, wpack, bias, res, out, out_v, G, N);
-    else conv_launch<256, 2, 4, 2>(st, act, wpack, bias, res, out, out_v, G, N);     // heads: N = 64 (35 real)
+    else if (G > 96) conv_sk_launch<2, 4>(st, act, wpack, bias, res, out, G, N, out_v);  // heads: N = 64 (35 real), split-K
+    else conv_sk_launch<2, 2>(st, act, wpack, bias, res, out, G, N, out_v);
 }
 
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G) {

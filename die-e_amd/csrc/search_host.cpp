@@ -28,6 +28,7 @@ struct SearchBufs {
     DevBuf<float> sel_value, policy, nn_value, noise, root_value0;
     DevBuf<uint8_t> leaf_term;
     DevBuf<unsigned long long> counters;
+    DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
     // games
     DevBuf<BgState> gstate;
@@ -104,7 +105,7 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
         B.policy.ensure((size_t)sc * 1352); B.nn_value.ensure(sc);
-        B.noise.ensure(1352); B.root_value0.ensure(4); B.counters.ensure(CNT_COUNT);
+        B.noise.ensure(1352); B.root_value0.ensure(4); B.counters.ensure(CNT_COUNT); B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
     }
     if (iterations + 1 > B.iter_cap) { B.iter_flags.ensure(2 * ((size_t)iterations + 1)); B.iter_cap = iterations + 1; }
@@ -115,7 +116,7 @@ Tree tree_view(SearchBufs& B) {
 }
 Slots slots_view(Engine& e, SearchBufs& B) {
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
-                 B.policy.p, B.nn_value.p, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, e.flags_dev.p};
+                 B.policy.p, B.nn_value.p, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
 }
 
 // alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round
@@ -139,6 +140,7 @@ void mcts_run(Engine& e, uint32_t n, const diee_mcts_cfg& cfg, uint64_t seed, ui
         nn_forward(e, B.eval_states.p, (int)n, B.policy.p, B.nn_value.p);   // alpha_mcts.rs:186
         launch_expand(st, T, S, n, it, P);
     }
+    launch_reduce_counters(st, S, n);
     HIPCHK(hipGetLastError());
 }
 

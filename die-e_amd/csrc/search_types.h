@@ -17,6 +17,8 @@ enum Counter {
     CNT_ILLEGAL, CNT_MAX_CHILDREN, CNT_PLIES, CNT_GAMES, CNT_COUNT
 };
 
+enum SlotCounter { SC_SELECTIONS = 0, SC_DEPTH_SUM, SC_TERMINAL, SC_EXPANSIONS, SC_CHILDREN, SC_MAX_CHILDREN, SC_ILLEGAL, SC_COUNT };
+
 struct Tree {
     float* visits;          // Node.visits  (f32 like the reference, node.rs:14)
     float* value;           // Node.value
@@ -43,7 +45,9 @@ struct Slots {
     float* noise;           // [1352] Dirichlet sample of this move-step
     float* root_value0;     // [1] NN value of slot 0's root
     uint32_t* iter_flags;   // [2*(iterations)] any_selected, stale-initial count per iteration
-    unsigned long long* counters;  // [CNT_COUNT]
+    unsigned long long* counters;  // [CNT_COUNT] totals (written by k_reduce_counters / single lanes only)
+    uint32_t* slot_cnt;     // [slots][SC_COUNT] per-slot counters of this move-step: same-address atomics from a
+                            // thousand waves serialise at ~11 ns each, per-slot words cost nothing
     uint32_t* overflow;     // capacity flag (bit0 sequence table, bit1 tree arena)
 };
 
