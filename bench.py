@@ -111,7 +111,8 @@ def main():
     dt = time.perf_counter() - t0
 
     keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
-            "conv_seconds", "conv_launches", "conv_flops", "fragments", "illegal_decodes"]
+            "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
+            "fragments", "illegal_decodes"]
     if dist is not None:
         dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
         tot.update(red)
@@ -119,7 +120,22 @@ def main():
     if rank == 0:
         games = tot["games"]
         exp_per_game = tot["expansions"] / max(games, 1)
-        achieved = tot["conv_flops"] / tot["conv_seconds"] / 1e12 if tot["conv_seconds"] else None
+        def roof(kernel, sec, launches, flops):
+            if not sec:
+                return None
+            a = flops / sec / 1e12
+            return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": a / PEAK_BF16_TFLOPS, "traffic": None, "launches_sampled": launches / world,
+                    "avg_launch_us": sec / max(launches, 1) * 1e6,
+                    "algorithmic_flops_per_launch": flops / max(launches, 1),
+                    "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"])}
+        # the tower of 38 3x3 convs is ~95 % of the GPU time; it runs as ONE fused launch (k_tower) while more
+        # than 500 games are alive and as 38 per-layer launches (k_conv3x3 / k_conv3x3_sk) below that
+        r_fused = roof("k_tower (38 fused 3x3 conv layers, one launch; batches > 500 boards)",
+                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"])
+        r_layer = roof("k_conv3x3<256,*> / k_conv3x3_sk (per-layer 3x3 tower conv; batches <= 500 boards)",
+                       tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
+        dominant, other = (r_fused, r_layer) if tot["tower_seconds"] >= tot["conv_seconds"] else (r_layer, r_fused)
         out = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -135,11 +151,7 @@ def main():
                       "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
                       "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"]},
-            "roofline": {"bound": "mfma", "kernel": "k_conv3x3<256,*> (3x3 tower conv, implicit GEMM)",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS if achieved else None, "traffic": None,
-                         "launches_sampled": tot["conv_launches"] / world,
-                         "avg_launch_us": tot["conv_seconds"] / max(tot["conv_launches"], 1) * 1e6},
+            "roofline": dominant, "roofline_other": other,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -115,18 +115,26 @@ void Engine::load_weights(const float* blob, size_t n) {
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
+    if (const char* v = getenv("DIEE_FUSED_MIN_GAMES")) net->fused_min_games = atoi(v);   // development / tests
     NetWeights& W = *net;
     std::vector<float> w, b;
     std::vector<uint16_t> pk;
+    W.wtower.ensure((size_t)38 * 8 * 144 * 64 * 8);
+    W.btower.ensure((size_t)38 * 256);
     auto up_conv = [&](int layer, const ConvOff& c, const BnOff& bn, int n_pad, int cin_pad) {
         fold(blob, c, bn, w, b);
         pack_conv(w, c.cout, c.cin, n_pad, cin_pad, pk);
-        W.wconv[layer].ensure(pk.size());
-        h2d(W.wconv[layer].p, pk.data(), pk.size());
         std::vector<float> bp(n_pad, 0.f);
         memcpy(bp.data(), b.data(), sizeof(float) * c.cout);
-        W.bconv[layer].ensure(n_pad);
-        h2d(W.bconv[layer].p, bp.data(), (size_t)n_pad);
+        if (layer >= 1 && layer <= 38) {
+            h2d(W.wl(layer), pk.data(), pk.size());
+            h2d(W.bl(layer), bp.data(), (size_t)n_pad);
+        } else {
+            W.wconv[layer].ensure(pk.size());
+            h2d(W.wconv[layer].p, pk.data(), pk.size());
+            W.bconv[layer].ensure(n_pad);
+            h2d(W.bconv[layer].p, bp.data(), (size_t)n_pad);
+        }
         sync();     // pk / bp are reused
     };
     up_conv(0, L.init_conv, L.init_bn, 256, 16);
@@ -190,14 +198,19 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
-    for (int i = 0; i < BLOCKS; ++i) {
-        launch_conv3x3(st, 256, 0, W.actX.p, W.wconv[1 + 2 * i].p, W.bconv[1 + 2 * i].p, nullptr, W.actH.p, nullptr, G, 256);
-        // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
-        launch_conv3x3(st, 256, 1, W.actH.p, W.wconv[2 + 2 * i].p, W.bconv[2 + 2 * i].p, W.actX.p, W.actX.p, nullptr, G, 256);
+    if (G > W.fused_min_games) {
+        launch_tower(st, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);          // all 38 layers, activations stay in LDS
+    } else {
+        for (int i = 0; i < BLOCKS; ++i) {
+            launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
+            // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
+            launch_conv3x3(st, 256, 1, W.actH.p, W.wl(2 + 2 * i), W.bl(2 + 2 * i), W.actX.p, W.actX.p, nullptr, G, 256);
+        }
     }
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, 38});
+        const bool fused = G > W.fused_min_games;
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, fused ? 1 : 38, fused});
     }
     launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
@@ -212,16 +225,21 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     for (auto& p : W.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            W.conv_seconds += ms * 1e-3; W.conv_launches += p.launches; W.conv_flops += p.flops;
+            if (p.fused) { W.tower_seconds += ms * 1e-3; W.tower_launches += p.launches; W.tower_flops += p.flops; }
+            else { W.conv_seconds += ms * 1e-3; W.conv_launches += p.launches; W.conv_flops += p.flops; }
         }
         W.free_events.push_back(p.a); W.free_events.push_back(p.b);
     }
     W.pending.clear();
-    if (stats) { stats->conv_seconds = W.conv_seconds; stats->conv_launches = W.conv_launches; stats->conv_flops = W.conv_flops; }
+    if (stats) {
+        stats->conv_seconds = W.conv_seconds; stats->conv_launches = W.conv_launches; stats->conv_flops = W.conv_flops;
+        stats->tower_seconds = W.tower_seconds; stats->tower_launches = W.tower_launches; stats->tower_flops = W.tower_flops;
+    }
 }
 void nn_reset_timing(Engine& e) {
     if (!e.net) return;
     e.net->conv_seconds = 0; e.net->conv_launches = 0; e.net->conv_flops = 0; e.net->forward_count = 0;
+    e.net->tower_seconds = 0; e.net->tower_launches = 0; e.net->tower_flops = 0;
 }
 
 // development probe: average device time of the tower conv kernel (modes 0 and 1) at batch G
@@ -242,7 +260,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
         for (int r = -3; r < reps; ++r) {
             if (r == 0) HIPCHK(hipEventRecord(a, st));
             const int layer = 1 + ((r + 3) % 38);
-            launch_conv3x3(st, 256, mode, mode ? W.actH.p : W.actX.p, W.wconv[layer].p, W.bconv[layer].p,
+            launch_conv3x3(st, 256, mode, mode ? W.actH.p : W.actX.p, W.wl(layer), W.bl(layer),
                            mode ? W.actX.p : nullptr, mode ? W.actX.p : W.actH.p, nullptr, G, 256);
         }
         HIPCHK(hipEventRecord(b, st));
@@ -254,11 +272,12 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     e.tmp_a.ensure((size_t)G * 32); e.tmp_b.ensure((size_t)G * 1352 * 4); e.tmp_c.ensure((size_t)G * 4);
     HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
     const int se = W.sample_every; W.sample_every = 0;
+    const int fm = W.fused_min_games; W.fused_min_games = variant == 100 ? 0 : (variant == 0 ? fm : 1 << 30);
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
         nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
     }
-    W.sample_every = se;
+    W.sample_every = se; W.fused_min_games = fm;
     HIPCHK(hipEventRecord(b, st));
     HIPCHK(hipEventSynchronize(b));
     HIPCHK(hipEventElapsedTime(&ms, a, b));

@@ -7,8 +7,13 @@
 namespace diee {
 
 struct NetWeights {
-    DevBuf<uint16_t> wconv[40];     // packed bf16 B fragments: 0 init, 1..38 tower, 39 heads
-    DevBuf<float> bconv[40];        // folded bias
+    DevBuf<uint16_t> wconv[40];     // packed bf16 B fragments: 0 init, 39 heads (1..38 live in wtower)
+    DevBuf<float> bconv[40];        // folded bias (1..38 live in btower)
+    DevBuf<uint16_t> wtower;        // [38][8][144][64][8] bf16: the tower layers, contiguous (fused tower kernel)
+    DevBuf<float> btower;           // [38][256]
+    uint16_t* wl(int layer) { return (layer >= 1 && layer <= 38) ? wtower.p + (size_t)(layer - 1) * 8 * 144 * 64 * 8 : wconv[layer].p; }
+    float* bl(int layer) { return (layer >= 1 && layer <= 38) ? btower.p + (size_t)(layer - 1) * 256 : bconv[layer].p; }
+    int fused_min_games = 500;      // batches above this run the tower as one launch
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias
     bool loaded = false;
@@ -17,13 +22,13 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; };
+    struct Pending { hipEvent_t a, b; double flops; int launches; bool fused; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     int sample_every = 17;
     uint64_t forward_count = 0;
-    double conv_seconds = 0, conv_flops = 0;
-    uint64_t conv_launches = 0;
+    double conv_seconds = 0, conv_flops = 0, tower_seconds = 0, tower_flops = 0;
+    uint64_t conv_launches = 0, tower_launches = 0;
     hipEvent_t get_event() {
         if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
         hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;

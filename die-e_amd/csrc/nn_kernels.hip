@@ -341,6 +341,128 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
     }
 }
 
+// Large-batch variant: the whole 38-layer tower in ONE launch.  A workgroup owns 4 boards and all 256
+// channels (4 waves x 2 N-fragments x 3 M-fragments), so a layer's output tile is exactly the next
+// layer's input tile: activations ping-pong between two LDS tiles and never leave the CU, the
+// residual is read from LDS, and the per-layer launch gap, tile staging and global epilogue (6.4 us
+// of a 27 us layer) disappear.  Weights stream L2 -> registers as in k_conv3x3, the ring of 9 x 2
+// fragments runs ahead across layer boundaries.  One __syncthreads() per layer.
+constexpr int kTowerLayerStride = 8 * 144 * 64;          // u32x4 per layer (1.18 MB)
+
+template <bool RES>
+__device__ __forceinline__ void tower_layer(char* tin, char* tout, const u32x4* wp, const u32x4* wp_next,
+                                            const float* __restrict__ bias, const int (&base)[9][3],
+                                            u32x4 (&bq)[9][2], int lane, int wave) {
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.0f;
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) a[0][f] = *(const bf16x8*)(tin + base[0][f]);
+    for (int it = 0; it < 8; ++it) {
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int t = u % 9, cur = u & 1, nxt = cur ^ 1, un = u + 1;
+            const int csn = it * 2 + un / 9;                  // 16 on the very last step: reads padding, unused
+#pragma unroll
+            for (int f = 0; f < 3; ++f) a[nxt][f] = *(const bf16x8*)(tin + base[un % 9][f] + csn * 32);
+            bf16x8 b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[t][q]);
+            {
+                const int cs_pf = it * 2 + u / 9 + 1;          // same tap, next channel step (of the next layer at the end)
+                const u32x4* src = cs_pf < 16 ? wp + (size_t)(cs_pf * 9 + t) * 64 : wp_next + (size_t)t * 64;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bq[t][q] = src[(size_t)q * 144 * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[f][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b[q], acc[f][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue straight into the other LDS tile (bf16 [row][channel], same padded layout)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = (wave * 2 + q) * 32 + (lane & 31);
+        const float bv = bias[n];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int off = r * 528 + n * 2;
+                float v = acc[f][q][i] + bv;
+                if (RES) v += bf2f(*(const uint16_t*)(tout + off));      // y = relu(conv2(h) + x), in place over x
+                v = v > 0.0f ? v : 0.0f;
+                *(uint16_t*)(tout + off) = f2bf(v);
+            }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_tower(const uint16_t* __restrict__ x_in,        // [M][256] bf16 (init block output)
+                                               const u32x4* __restrict__ wt,           // [38][8][144][64] x 16 B
+                                               const float* __restrict__ bias,         // [38][256]
+                                               uint16_t* __restrict__ x_out, int M) {
+    constexpr int ROWS = 96, RS = 528, TILE = (ROWS + 1) * RS + 16 * 34 + 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tx = smem;
+    char* th = smem + (TILE + 15) / 16 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS;
+
+    const u32x4* wp0 = wt + (size_t)(wave * 2) * 144 * 64 + lane;
+    u32x4 bq[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bq[t][q] = wp0[((size_t)q * 144 + t) * 64];
+
+    for (int i = tid; i < ROWS * 32; i += 256) {
+        const int r = i >> 5, ch = i & 31;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + r < M) v = *(const u32x4*)(x_in + (size_t)(row0 + r) * 256 + ch * 8);
+        *(u32x4*)(tx + r * RS + ch * 16) = v;
+    }
+    for (int i = tid; i < 2 * 36; i += 256) {                 // zero rows of both tiles (+ over-read slack)
+        char* tl = i < 36 ? tx : th;
+        *(u32x4*)(tl + ROWS * RS + (i % 36) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    int base[9][3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int R = 32 * f + (lane & 31);
+        const int p = R % 24, y = p / 6, x = p % 6;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            base[t][f] = (ok ? R + 6 * dy + dx : ROWS) * RS + (lane >> 5) * 16;
+        }
+    }
+    __syncthreads();
+
+    for (int blk = 0; blk < 19; ++blk) {
+        const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTowerLayerStride;
+        const u32x4* w2 = w1 + kTowerLayerStride;
+        const u32x4* w3 = blk < 18 ? w2 + kTowerLayerStride : w2;       // after the last layer: harmless re-read
+        tower_layer<false>(tx, th, w1, w2, bias + (2 * blk) * 256, base, bq, lane, wave);
+        tower_layer<true>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, base, bq, lane, wave);
+    }
+    for (int i = tid; i < ROWS * 32; i += 256) {
+        const int r = i >> 5, ch = i & 31;
+        if (row0 + r < M) *(u32x4*)(x_out + (size_t)(row0 + r) * 256 + ch * 8) = *(const u32x4*)(tx + r * RS + ch * 16);
+    }
+}
+
 // policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight
 // from L2 (the layer is ~0.2 % of the network's FLOPs).
 __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
@@ -448,6 +570,18 @@ static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpac
     }
     hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT>), dim3((G + GT - 1) / GT, N / 32), dim3(256), lds, st, act,
                        (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
+}
+
+// the whole tower in one launch (4 boards per workgroup); x_in/x_out may alias
+void launch_tower(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
+    static bool attr_set = false;
+    constexpr int tile = ((96 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
+    constexpr int lds = 2 * tile;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_tower, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tower, dim3((G + 3) / 4), dim3(256), lds, st, x_in, (const u32x4*)wt, bias, x_out, G * 24);
 }
 
 void nn_setup_kernels() {}

@@ -85,9 +85,12 @@ typedef struct {
     uint64_t fragments;
     double   seconds;          /* wall clock of the call, inputs resident                  */
     double   nn_seconds;       /* HIP-event time of the ResNet kernels                     */
-    double   conv_seconds;     /* HIP-event time of the 3x3 tower conv kernel alone        */
-    uint64_t conv_launches;    /* launches of that kernel                                  */
+    double   conv_seconds;     /* HIP-event time of sampled per-layer tower conv launches   */
+    uint64_t conv_launches;    /* sampled launches of k_conv3x3 / k_conv3x3_sk (tower)      */
     double   conv_flops;       /* algorithmic FLOPs those launches performed               */
+    double   tower_seconds;    /* HIP-event time of sampled fused-tower launches (k_tower)  */
+    uint64_t tower_launches;
+    double   tower_flops;
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */

@@ -84,3 +84,25 @@ def test_scaled_weights_stress_tolerance(setup, oracle):
     assert rel <= np.expm1(0.006 * spread)
     assert np.abs(val - rv).max() <= VALUE_ATOL
     e2.close()
+
+
+def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
+    """large batches run the 38-layer tower as one launch (activations stay in LDS); the arithmetic per
+    element is the same as the per-layer kernels of the same geometry class, so results are bit-identical"""
+    import diee_amd
+    from oracle.nn_ref import parse, forward_t
+    blob = diee_amd.random_weights(0)
+    states = oracle.random_walk_states(21, 12)[:700]
+    assert len(states) == 700
+    monkeypatch.setenv("DIEE_FUSED_MIN_GAMES", "0")
+    e1 = diee_amd.Engine(0); e1.load_weights(blob)
+    p1, v1 = e1.forward_t(states)                 # fused (700 > 0)
+    p1s, v1s = e1.forward_t(states[:5])           # fused, ragged small batch (5 boards: padded workgroup)
+    monkeypatch.setenv("DIEE_FUSED_MIN_GAMES", "1000000")
+    e2 = diee_amd.Engine(0); e2.load_weights(blob)
+    p2, v2 = e2.forward_t(states)                 # per-layer kernels, 4 boards x 128 channels
+    assert (p1 == p2).all() and (v1 == v2).all()
+    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:40]))
+    assert np.abs(p1[:40] - rp).max() <= POLICY_ATOL and np.abs(v1[:40] - rv).max() <= VALUE_ATOL
+    assert np.abs(p1s - rp[:5]).max() <= POLICY_ATOL and np.abs(v1s - rv[:5]).max() <= VALUE_ATOL
+    e1.close(); e2.close()
