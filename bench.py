@@ -74,7 +74,7 @@ def main():
     ddist = importlib.import_module("die-e_amd.dist")
     rank, local_rank, world = ddist.rank_world()
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
