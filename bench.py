@@ -120,19 +120,28 @@ def main():
     if rank == 0:
         games = tot["games"]
         exp_per_game = tot["expansions"] / max(games, 1)
-        def roof(kernel, sec, launches, flops):
+        def pmc_traffic(name):
+            # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            # (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), at 1024 boards
+            try:
+                doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                return doc["kernels"][name]["hbm_side_bytes_per_launch_corrected"]
+            except Exception:
+                return None
+
+        def roof(kernel, sec, launches, flops, traffic=None):
             if not sec:
                 return None
             a = flops / sec / 1e12
             return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": a / PEAK_BF16_TFLOPS, "traffic": None, "launches_sampled": launches / world,
+                    "frac": a / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_sampled": launches / world,
                     "avg_launch_us": sec / max(launches, 1) * 1e6,
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
                     "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"])}
         # the tower of 38 3x3 convs is ~95 % of the GPU time; it runs as ONE fused launch (k_tower) while more
         # than 500 games are alive and as 38 per-layer launches (k_conv3x3 / k_conv3x3_sk) below that
         r_fused = roof("k_tower (38 fused 3x3 conv layers, one launch; batches > 500 boards)",
-                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"])
+                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower"))
         r_layer = roof("k_conv3x3<256,*> / k_conv3x3_sk (per-layer 3x3 tower conv; batches <= 500 boards)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         dominant, other = (r_fused, r_layer) if tot["tower_seconds"] >= tot["conv_seconds"] else (r_layer, r_fused)
