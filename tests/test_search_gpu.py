@@ -66,6 +66,23 @@ def test_mcts_batch_bit_exact(eng, oracle, n, iters, pick, quirks):
         assert os_["terminal_hits"] > 0          # the terminal / stale-slot paths were exercised
 
 
+@pytest.mark.parametrize("n,iters", [(4, 400), (2, 1600)])
+def test_deep_tree_configs_bit_exact(eng, oracle, n, iters):
+    """BASELINE configs[2] (iterations=400) and configs[3] (iterations=1600 deep tree) at reduced N"""
+    walk = oracle.random_walk_states(31, 6)
+    states = walk[50:50 + 9 * n:9]
+    ocfg, gcfg = cfgs(oracle, iters)
+    ev, _ = gpu_eval(eng, oracle)
+    gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
+    roots, probs, ostats, n_nodes = oracle.alpha_mcts_parallel(1, states, ocfg, ev, None, SEED, 0, gids, rds, 1)
+    r = eng.alpha_mcts_parallel(states, gcfg, SEED, 0, gids, rds, ref_quirks=True)
+    assert r["probs"].tobytes() == probs.tobytes()
+    gs, os_ = r["stats"], ostats.as_dict()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert gs[key] == os_[key], (key, gs[key], os_[key])
+    assert gs["depth_sum"] / gs["selections"] > 1.5          # beyond the root level (uniform-ish priors give wide trees)
+
+
 def test_self_play_bit_exact(eng, oracle):
     """whole games: records, policy targets (visits/sum)^(1/T) and outcomes identical to the oracle"""
     n, iters = 12, 12
