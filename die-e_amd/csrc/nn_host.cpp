@@ -116,6 +116,7 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_FUSED_MIN_GAMES")) net->fused_min_games = atoi(v);   // development / tests
+    if (const char* v = getenv("DIEE_FUSED2_MIN_GAMES")) net->fused2_min_games = atoi(v);
     NetWeights& W = *net;
     std::vector<float> w, b;
     std::vector<uint16_t> pk;
@@ -199,7 +200,9 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
     if (G > W.fused_min_games) {
-        launch_tower(st, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);          // all 38 layers, activations stay in LDS
+        launch_tower(st, 0, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);       // all 38 layers, activations stay in LDS
+    } else if (G > W.fused2_min_games) {
+        launch_tower(st, 1, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);
     } else {
         for (int i = 0; i < BLOCKS; ++i) {
             launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
@@ -209,7 +212,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     }
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        const bool fused = G > W.fused_min_games;
+        const bool fused = G > W.fused_min_games || G > W.fused2_min_games;
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, fused ? 1 : 38, fused});
     }
     launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
@@ -272,12 +275,14 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     e.tmp_a.ensure((size_t)G * 32); e.tmp_b.ensure((size_t)G * 1352 * 4); e.tmp_c.ensure((size_t)G * 4);
     HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
     const int se = W.sample_every; W.sample_every = 0;
-    const int fm = W.fused_min_games; W.fused_min_games = variant == 100 ? 0 : (variant == 0 ? fm : 1 << 30);
+    const int fm = W.fused_min_games, fm2 = W.fused2_min_games;
+    W.fused_min_games = variant == 100 ? 0 : (variant == 0 ? fm : 1 << 30);
+    W.fused2_min_games = variant == 101 ? 0 : (variant == 0 ? fm2 : 1 << 30);
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
         nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
     }
-    W.sample_every = se; W.fused_min_games = fm;
+    W.sample_every = se; W.fused_min_games = fm; W.fused2_min_games = fm2;
     HIPCHK(hipEventRecord(b, st));
     HIPCHK(hipEventSynchronize(b));
     HIPCHK(hipEventElapsedTime(&ms, a, b));

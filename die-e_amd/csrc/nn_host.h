@@ -13,7 +13,8 @@ struct NetWeights {
     DevBuf<float> btower;           // [38][256]
     uint16_t* wl(int layer) { return (layer >= 1 && layer <= 38) ? wtower.p + (size_t)(layer - 1) * 8 * 144 * 64 * 8 : wconv[layer].p; }
     float* bl(int layer) { return (layer >= 1 && layer <= 38) ? btower.p + (size_t)(layer - 1) * 256 : bconv[layer].p; }
-    int fused_min_games = 500;      // batches above this run the tower as one launch
+    int fused_min_games = 560;      // batches above this run the tower as one launch (4 boards per workgroup)
+    int fused2_min_games = 272;     // batches above this (and <= fused_min_games): one launch, 2 boards per workgroup
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias
     bool loaded = false;

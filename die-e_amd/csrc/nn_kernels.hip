@@ -349,55 +349,59 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
 // fragments runs ahead across layer boundaries.  One __syncthreads() per layer.
 constexpr int kTowerLayerStride = 8 * 144 * 64;          // u32x4 per layer (1.18 MB)
 
-template <bool RES>
+// One tower layer inside the fused kernel.  GT boards per workgroup (MF M-fragments), NF N-fragments
+// per wave, PF = weight fragments in flight per wave and N-fragment (k-steps ahead; 9 or 18).
+template <bool RES, int GT, int NF, int PF>
 __device__ __forceinline__ void tower_layer(char* tin, char* tout, const u32x4* wp, const u32x4* wp_next,
-                                            const float* __restrict__ bias, const int (&base)[9][3],
-                                            u32x4 (&bq)[9][2], int lane, int wave) {
-    f32x16 acc[3][2];
+                                            const float* __restrict__ bias, const int (&base)[9][(GT * 24 + 31) / 32],
+                                            u32x4 (&bq)[PF][NF], int lane, int wave) {
+    constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
+    f32x16 acc[MF][NF];
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
+    for (int f = 0; f < MF; ++f)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NF; ++q)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.0f;
-    bf16x8 a[2][3];
+    bf16x8 a[2][MF];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) a[0][f] = *(const bf16x8*)(tin + base[0][f]);
+    for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(tin + base[0][f]);
     for (int it = 0; it < 8; ++it) {
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
             const int t = u % 9, cur = u & 1, nxt = cur ^ 1, un = u + 1;
             const int csn = it * 2 + un / 9;                  // 16 on the very last step: reads padding, unused
 #pragma unroll
-            for (int f = 0; f < 3; ++f) a[nxt][f] = *(const bf16x8*)(tin + base[un % 9][f] + csn * 32);
-            bf16x8 b[2];
+            for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(tin + base[un % 9][f] + csn * 32);
+            bf16x8 b[NF];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[t][q]);
+            for (int q = 0; q < NF; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
             {
-                const int cs_pf = it * 2 + u / 9 + 1;          // same tap, next channel step (of the next layer at the end)
-                const u32x4* src = cs_pf < 16 ? wp + (size_t)(cs_pf * 9 + t) * 64 : wp_next + (size_t)t * 64;
+                const int cs_pf = it * 2 + u / 9 + PF / 9;     // same tap, PF/9 channel steps ahead (next layer at the end)
+                const u32x4* src = cs_pf < 16 ? wp + (size_t)(cs_pf * 9 + t) * 64 : wp_next + (size_t)((cs_pf - 16) * 9 + t) * 64;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bq[t][q] = src[(size_t)q * 144 * 64];
+                for (int q = 0; q < NF; ++q) bq[u % PF][q] = src[(size_t)q * 144 * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < 3; ++f)
+            for (int f = 0; f < MF; ++f)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < NF; ++q)
                     acc[f][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b[q], acc[f][q], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // epilogue straight into the other LDS tile (bf16 [row][channel], same padded layout)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int n = (wave * 2 + q) * 32 + (lane & 31);
+    for (int q = 0; q < NF; ++q) {
+        const int n = (wave * NF + q) * 32 + (lane & 31);
         const float bv = bias[n];
 #pragma unroll
-        for (int f = 0; f < 3; ++f)
+        for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (ROWS % 32 != 0 && r >= ROWS) continue;
                 const int off = r * 528 + n * 2;
                 float v = acc[f][q][i] + bv;
                 if (RES) v += bf2f(*(const uint16_t*)(tout + off));      // y = relu(conv2(h) + x), in place over x
@@ -408,43 +412,46 @@ __device__ __forceinline__ void tower_layer(char* tin, char* tout, const u32x4* 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_tower(const uint16_t* __restrict__ x_in,        // [M][256] bf16 (init block output)
-                                               const u32x4* __restrict__ wt,           // [38][8][144][64] x 16 B
-                                               const float* __restrict__ bias,         // [38][256]
-                                               uint16_t* __restrict__ x_out, int M) {
-    constexpr int ROWS = 96, RS = 528, TILE = (ROWS + 1) * RS + 16 * 34 + 128;
+// GT boards x all 256 channels per workgroup: 256 / (32 * NF) waves.
+template <int GT, int NF, int PF>
+__global__ __launch_bounds__(64 * (8 / NF)) void k_tower(const uint16_t* __restrict__ x_in,   // [M][256] bf16 (init block output)
+                                                         const u32x4* __restrict__ wt,      // [38][8][144][64] x 16 B
+                                                         const float* __restrict__ bias,    // [38][256]
+                                                         uint16_t* __restrict__ x_out, int M) {
+    constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, NT = 64 * (8 / NF);
+    constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tx = smem;
-    char* th = smem + (TILE + 15) / 16 * 16;
+    char* th = smem + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
 
-    const u32x4* wp0 = wt + (size_t)(wave * 2) * 144 * 64 + lane;
-    u32x4 bq[9][2];
+    const u32x4* wp0 = wt + (size_t)(wave * NF) * 144 * 64 + lane;
+    u32x4 bq[PF][NF];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < PF; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) bq[t][q] = wp0[((size_t)q * 144 + t) * 64];
+        for (int q = 0; q < NF; ++q) bq[i][q] = wp0[((size_t)q * 144 + i) * 64];
 
-    for (int i = tid; i < ROWS * 32; i += 256) {
+    for (int i = tid; i < ROWS * 32; i += NT) {
         const int r = i >> 5, ch = i & 31;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row0 + r < M) v = *(const u32x4*)(x_in + (size_t)(row0 + r) * 256 + ch * 8);
         *(u32x4*)(tx + r * RS + ch * 16) = v;
     }
-    for (int i = tid; i < 2 * 36; i += 256) {                 // zero rows of both tiles (+ over-read slack)
+    for (int i = tid; i < 2 * 36; i += NT) {                  // zero rows of both tiles (+ over-read slack)
         char* tl = i < 36 ? tx : th;
         *(u32x4*)(tl + ROWS * RS + (i % 36) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
-    int base[9][3];
+    int base[9][MF];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < MF; ++f) {
         const int R = 32 * f + (lane & 31);
         const int p = R % 24, y = p / 6, x = p % 6;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool ok = (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
             base[t][f] = (ok ? R + 6 * dy + dx : ROWS) * RS + (lane >> 5) * 16;
         }
     }
@@ -454,10 +461,10 @@ __global__ __launch_bounds__(256) void k_tower(const uint16_t* __restrict__ x_in
         const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTowerLayerStride;
         const u32x4* w2 = w1 + kTowerLayerStride;
         const u32x4* w3 = blk < 18 ? w2 + kTowerLayerStride : w2;       // after the last layer: harmless re-read
-        tower_layer<false>(tx, th, w1, w2, bias + (2 * blk) * 256, base, bq, lane, wave);
-        tower_layer<true>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, base, bq, lane, wave);
+        tower_layer<false, GT, NF, PF>(tx, th, w1, w2, bias + (2 * blk) * 256, base, bq, lane, wave);
+        tower_layer<true, GT, NF, PF>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, base, bq, lane, wave);
     }
-    for (int i = tid; i < ROWS * 32; i += 256) {
+    for (int i = tid; i < ROWS * 32; i += NT) {
         const int r = i >> 5, ch = i & 31;
         if (row0 + r < M) *(u32x4*)(x_out + (size_t)(row0 + r) * 256 + ch * 8) = *(const u32x4*)(tx + r * RS + ch * 16);
     }
@@ -572,16 +579,23 @@ static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpac
                        (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
 }
 
-// the whole tower in one launch (4 boards per workgroup); x_in/x_out may alias
-void launch_tower(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
+// the whole tower in one launch; x_in/x_out may alias.  geometry 0: 4 boards x (4 waves x 2 N-fragments),
+// 1: 2 boards x (8 waves x 1 N-fragment, 18 weight fragments in flight) for mid-size batches
+template <int GT, int NF, int PF>
+static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
     static bool attr_set = false;
-    constexpr int tile = ((96 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
+    constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_tower, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_tower<GT, NF, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tower, dim3((G + 3) / 4), dim3(256), lds, st, x_in, (const u32x4*)wt, bias, x_out, G * 24);
+    hipLaunchKernelGGL((k_tower<GT, NF, PF>), dim3((G + GT - 1) / GT), dim3(64 * (8 / NF)), lds, st, x_in,
+                       (const u32x4*)wt, bias, x_out, G * 24);
+}
+void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
+    if (geometry == 0) tower_launch<4, 2, 9>(st, x_in, wt, bias, x_out, G);
+    else tower_launch<2, 1, 18>(st, x_in, wt, bias, x_out, G);
 }
 
 void nn_setup_kernels() {}
@@ -600,7 +614,7 @@ static int pick_variant(int G) {
     // measured (scripts/conv_sweep.py, MI355X, us per launch): large batches are throughput-bound and want
     // 4 boards x 128 channels per workgroup (up to 3 workgroups per CU); small batches are latency-bound
     // and want the split-K geometry (8x more workgroups, 4x shorter dependent chains)
-    if (G > 320) return 2;          // 4 boards x 128 channels, 4 waves
+    if (G > 320) return 2;          // 4 boards x 128 channels, 4 waves (only reached when the fused tower is disabled)
     if (G > 80) return 6;           // split-K, 4 boards x 32 channels
     return 5;                       // split-K, 2 boards x 32 channels
 }

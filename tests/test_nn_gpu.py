@@ -99,6 +99,14 @@ def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
     p1, v1 = e1.forward_t(states)                 # fused (700 > 0)
     p1s, v1s = e1.forward_t(states[:5])           # fused, ragged small batch (5 boards: padded workgroup)
     monkeypatch.setenv("DIEE_FUSED_MIN_GAMES", "1000000")
+    monkeypatch.setenv("DIEE_FUSED2_MIN_GAMES", "0")
+    e3 = diee_amd.Engine(0); e3.load_weights(blob)
+    p3, v3 = e3.forward_t(states)                 # fused, 2 boards per workgroup (mid-size batches)
+    assert (p1 == p3).all() and (v1 == v3).all()
+    p3s, v3s = e3.forward_t(states[:5])
+    assert (p3s == p1s).all() and (v3s == v1s).all()
+    e3.close()
+    monkeypatch.setenv("DIEE_FUSED2_MIN_GAMES", "1000000")
     e2 = diee_amd.Engine(0); e2.load_weights(blob)
     p2, v2 = e2.forward_t(states)                 # per-layer kernels, 4 boards x 128 channels
     assert (p1 == p2).all() and (v1 == v2).all()
