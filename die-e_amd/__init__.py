@@ -142,6 +142,9 @@ class Engine:
     """one engine per GPU (diee_ctx)"""
 
     def __init__(self, device=0, game_id=GAME_BACKGAMMON):
+        import sys
+        if "torch" in sys.modules:          # see alphazero.py: torch's bundled HIP runtime must initialise first
+            sys.modules["torch"].cuda.is_available()
         self._L = load_library()
         h = C.c_void_p()
         st = self._L.diee_create(device, game_id, C.byref(h))

@@ -1,0 +1,308 @@
+"""Host-side callers of the hot path, mirroring the reference's driver layer (SURVEY section 8(f) rows
+F1, F3, F4): AlphaZero::{from_config, self_play_parallel, train, learn_parallel, save/load_training_data,
+play_vs_best_model} (src/alphazero/alphazero.rs, alpha_parallel.rs, alpha_versus.rs).
+
+Self-play and model-vs-model search run on the HIP engine through the C ABI.  The training step is
+PyTorch-ROCm (the reference's is tch/libtorch autograd; SURVEY: "do it in PyTorch-ROCm, not
+hand-written backward"), data-parallel over ranks with DistributedDataParallel on RCCL.  Tensors are
+stored as .npy instead of libtorch .ot archives (F3: a converter, not a native reader, is the plan).
+"""
+import os
+import secrets
+import time
+
+import numpy as np
+import torch
+
+from . import BG_ACTIONS, BG_PLANES, Engine, MctsConfig, random_weights
+
+# PyTorch bundles its own HIP runtime; it has to initialise BEFORE libdiee.so's (system ROCm) runtime does,
+# otherwise torch.cuda reports no device.  Importing this module first (the CLI and the learn loop do) is enough.
+TORCH_CUDA = torch.cuda.is_available()
+
+try:                       # Python 3.11+
+    import tomllib as _toml
+except ImportError:        # this image: Python 3.10 + tomli
+    import tomli as _toml
+
+
+# --------------------------------------------------------------------------- config (alphazero.rs:25-59, lib.rs:43-51)
+CONFIG_KEYS = ("temperature", "learn_iterations", "num_epochs", "training_batch_size", "self_play_iterations",
+               "num_self_play_batches", "iterations", "exploration_const", "simulate_round_limit",
+               "dirichlet_alpha", "dirichlet_epsilon", "wd", "lr")
+
+
+def load_config(path):
+    """the reference loads `-c FILE` as TOML through the `config` crate (main.rs:88-98); 13 flat keys"""
+    with open(path, "rb") as f:
+        conf = _toml.load(f)
+    missing = [k for k in CONFIG_KEYS if k not in conf]
+    if missing:
+        raise KeyError(f"Unable to load config, missing keys: {missing}")      # from_config panics, alphazero.rs:113-127
+    return conf
+
+
+class AlphaZeroConfig:
+    def __init__(self, temperature, learn_iterations, self_play_iterations, num_epochs, training_batch_size,
+                 num_self_play_batches):
+        self.temperature = float(temperature)
+        self.learn_iterations = int(learn_iterations)
+        self.self_play_iterations = int(self_play_iterations)
+        self.num_epochs = int(num_epochs)
+        self.training_batch_size = int(training_batch_size)
+        self.num_self_play_batches = int(num_self_play_batches)
+
+    @classmethod
+    def from_config(cls, conf):                                                 # alphazero.rs:35-44
+        return cls(conf["temperature"], conf["learn_iterations"], conf["self_play_iterations"], conf["num_epochs"],
+                   conf["training_batch_size"], conf["num_self_play_batches"])
+
+
+def mcts_config_from(conf):                                                     # lib.rs:43-51
+    return MctsConfig(iterations=int(conf["iterations"]), c=float(conf["exploration_const"]),
+                      round_limit=int(conf["simulate_round_limit"]), dir_alpha=float(conf["dirichlet_alpha"]),
+                      dir_eps=float(conf["dirichlet_epsilon"]))
+
+
+class OptimizerParams:                                                          # alphazero.rs:48-59
+    def __init__(self, wd, lr):
+        self.wd, self.lr = float(wd), float(lr)
+
+    @classmethod
+    def from_config(cls, conf):
+        return cls(conf["wd"], conf["lr"])
+
+
+# --------------------------------------------------------------------------- trainable ResNet (nnet.rs:24-34,57-155)
+def make_resnet():
+    import torch
+    from torch import nn
+
+    F, BLOCKS, A = 256, 19, BG_ACTIONS
+
+    class ResBlock(nn.Module):                                                  # nnet.rs:16-46
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(F, F, 3, padding=1); self.conv2 = nn.Conv2d(F, F, 3, padding=1)
+            self.bn1 = nn.BatchNorm2d(F); self.bn2 = nn.BatchNorm2d(F)
+
+        def forward(self, x):
+            h = torch.relu(self.bn1(self.conv1(x)))
+            return torch.relu(self.bn2(self.conv2(h)) + x)
+
+    class ResNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.init_conv = nn.Conv2d(6, F, 3, padding=1); self.init_bn = nn.BatchNorm2d(F)
+            self.blocks = nn.ModuleList([ResBlock() for _ in range(BLOCKS)])
+            self.p_conv = nn.Conv2d(F, 32, 3, padding=1); self.p_bn = nn.BatchNorm2d(32); self.p_fc = nn.Linear(768, A)
+            self.v_conv = nn.Conv2d(F, 3, 3, padding=1); self.v_bn = nn.BatchNorm2d(3); self.v_fc = nn.Linear(72, 1)
+
+        def forward_train(self, x):
+            """raw policy logits + tanh value (nnet.rs:137-148; the value head's tanh is inside the head)"""
+            x = torch.relu(self.init_bn(self.init_conv(x)))
+            for b in self.blocks:
+                x = b(x)
+            logits = self.p_fc(torch.relu(self.p_bn(self.p_conv(x))).flatten(1))
+            value = torch.tanh(self.v_fc(torch.relu(self.v_bn(self.v_conv(x))).flatten(1)))
+            return logits, value
+
+        forward = forward_train
+
+        def _tensors(self):
+            """the blob order of include/diee.h (creation order of nnet.rs:62-97)"""
+            def conv(c): return [c.weight, c.bias]
+            def bn(b): return [b.weight, b.bias, b.running_mean, b.running_var]
+            out = conv(self.init_conv) + bn(self.init_bn)
+            for b in self.blocks:
+                out += conv(b.conv1) + conv(b.conv2) + bn(b.bn1) + bn(b.bn2)
+            out += conv(self.p_conv) + bn(self.p_bn) + [self.p_fc.weight, self.p_fc.bias]
+            out += conv(self.v_conv) + bn(self.v_bn) + [self.v_fc.weight, self.v_fc.bias]
+            return out
+
+        @torch.no_grad()
+        def load_blob(self, blob):
+            t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.float32))
+            o = 0
+            for p in self._tensors():
+                n = p.numel()
+                p.copy_(t[o:o + n].reshape(p.shape)); o += n
+            assert o == t.numel(), (o, t.numel())
+            return self
+
+        @torch.no_grad()
+        def to_blob(self):
+            return torch.cat([p.detach().float().reshape(-1).cpu() for p in self._tensors()]).numpy()
+
+    return ResNet()
+
+
+# --------------------------------------------------------------------------- AlphaZero (alphazero.rs:61-67)
+class AlphaZero:
+    def __init__(self, engine, config, mcts_config, op, blob=None, train_device=None, seed=0xD1EE0001,
+                 rank=0, world=1, root=".", quiet=False):
+        import torch
+        self.engine, self.config, self.mcts_config, self.op = engine, config, mcts_config, op
+        self.rank, self.world, self.root, self.quiet = rank, world, root, quiet
+        self.seed = seed
+        self.calls = 0
+        self.blob = np.ascontiguousarray(blob if blob is not None else random_weights(0), dtype=np.float32)
+        if engine is not None:
+            engine.load_weights(self.blob)
+        self.device = train_device or ("cuda" if TORCH_CUDA else "cpu")
+        self.model = make_resnet().load_blob(self.blob).to(self.device)
+        self.ddp = None
+        if world > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            self.ddp = DDP(self.model, device_ids=[torch.cuda.current_device()] if self.device == "cuda" else None)
+        # Adam::default().wd(op.wd).build(&vs, op.lr), alphazero.rs:102 (L2 added to the gradient, not AdamW)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=op.lr, betas=(0.9, 0.999), eps=1e-8,
+                                          weight_decay=op.wd)
+
+    @classmethod
+    def from_config(cls, engine, conf, model_path=None, **kw):                   # alphazero.rs:113-127, :81-100
+        blob = None
+        best = os.path.join(kw.get("root", "."), "models", "backgammon", "best_model.npy")
+        if model_path:
+            blob = np.load(model_path)
+        elif os.path.exists(best):
+            blob = np.load(best)
+        return cls(engine, AlphaZeroConfig.from_config(conf), mcts_config_from(conf), OptimizerParams.from_config(conf),
+                   blob=blob, **kw)
+
+    def log(self, *a):
+        if not self.quiet and self.rank == 0:
+            print(*a, flush=True)
+
+    # ---- self_play_parallel, alpha_parallel.rs:101-231 (the hot path, on the HIP engine) ----
+    def self_play_parallel(self):
+        n = self.config.num_self_play_batches
+        self.calls += 1
+        out = self.engine.self_play_parallel(n, self.mcts_config, self.config.temperature,
+                                             seed=self.seed + 0x9E3779B1 * self.calls, ref_quirks=True,
+                                             first_game_id=self.rank * n)
+        self.last_stats = out["stats"]
+        return {"outcome": out["outcome"], "ps": out["ps"], "state": out["state"]}
+
+    # ---- save/load_training_data, alphazero.rs:149-200 (ps [M,1352], states [M,6,4,6], outcomes [M] i8) ----
+    @staticmethod
+    def save_training_data(memory, path):
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"path: {path} does not exist!")
+        np.save(os.path.join(path, "ps.npy"), memory["ps"])
+        np.save(os.path.join(path, "states.npy"), memory["state"].reshape(-1, 6, 4, 6))
+        np.save(os.path.join(path, "outcomes.npy"), memory["outcome"].astype(np.int8))
+
+    @staticmethod
+    def load_training_data(path):
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"path: {path} does not exist!")
+        return {"ps": np.load(os.path.join(path, "ps.npy")),
+                "state": np.load(os.path.join(path, "states.npy")).reshape(-1, BG_PLANES),
+                "outcome": np.load(os.path.join(path, "outcomes.npy"))}
+
+    @staticmethod
+    def concat(mems):
+        mems = [m for m in mems if len(m["outcome"])]
+        if not mems:
+            return {"outcome": np.zeros(0, np.int8), "ps": np.zeros((0, BG_ACTIONS), np.float32),
+                    "state": np.zeros((0, BG_PLANES), np.float32)}
+        return {k: np.concatenate([m[k] for m in mems]) for k in ("outcome", "ps", "state")}
+
+    # ---- train, alphazero.rs:202-261 ----
+    def train(self, memory, rng=None):
+        import torch
+        import torch.nn.functional as Fn
+        n = len(memory["outcome"])
+        rng = rng or np.random.default_rng(self.seed + self.calls)
+        perm = rng.permutation(n)                                               # memory.shuffle(&mut rng), :203-204
+        net = self.ddp or self.model
+        net.train()                                                             # forward_train(.., true): BN batch statistics
+        losses = []
+        bs = self.config.training_batch_size
+        for b0 in range(0, n, bs):                                              # :205-206
+            idx = perm[b0:b0 + bs]
+            st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6).to(self.device)
+            ps = torch.from_numpy(memory["ps"][idx]).to(self.device)
+            oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1).to(self.device)
+            logits, value = net(st)
+            policy_loss = Fn.cross_entropy(logits, ps)                          # soft targets = un-renormalised ps (Q17), :239-245
+            outcome_loss = Fn.mse_loss(value, oc)                               # :246
+            loss = policy_loss + outcome_loss
+            if not torch.isfinite(loss):
+                raise FloatingPointError("Total loss is nan or inf!")          # :248-255
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            losses.append(float(loss.detach()))
+        return losses
+
+    def sync_engine(self):
+        """fold the trained weights back into the HIP engine (BN running statistics included)"""
+        self.model.eval()
+        self.blob = self.model.to_blob()
+        if not np.isfinite(self.blob).all():
+            raise FloatingPointError("nan variables detected!")                 # alpha_parallel.rs:83
+        if self.engine is not None:
+            self.engine.load_weights(self.blob)
+
+    # ---- learn_parallel, alpha_parallel.rs:17-99 ----
+    def learn_parallel(self, arena=True, arena_games=400):
+        run_id = secrets.token_urlsafe(16)[:21]                                 # nanoid!()
+        base = os.path.join(self.root, "data", "backgammon", f"run-{run_id}")
+        if self.rank == 0:
+            os.makedirs(base, exist_ok=True)
+        self.log(f"Staring up run with run_id: {run_id}")
+        report = []
+        for l_i in range(self.config.learn_iterations):                         # :41
+            lrn = os.path.join(base, f"lrn-{l_i}")
+            memory = []
+            t_sp = time.time()
+            for sp_i in range(self.config.self_play_iterations):                # :49
+                memory.append(self.self_play_parallel())
+                if self.rank == 0:
+                    sp_dir = os.path.join(lrn, f"sp-{sp_i}")
+                    os.makedirs(sp_dir, exist_ok=True)
+                    self.save_training_data(self.concat(memory), sp_dir)        # cumulative memory (Q20), :53,62
+            t_sp = time.time() - t_sp
+            mem = self.concat(memory)
+            t_tr = time.time()
+            losses = []
+            for _ in range(self.config.num_epochs):                             # :78-81
+                losses += self.train(mem)
+            self.sync_engine()
+            t_tr = time.time() - t_tr
+            if self.rank == 0:
+                mdir = os.path.join(self.root, "models", "backgammon")
+                os.makedirs(mdir, exist_ok=True)
+                np.save(os.path.join(mdir, f"model_{l_i}.npy"), self.blob)      # :85-95
+                self.log(f"Iteration {l_i} saved successfully; {len(mem['outcome'])} fragments, self-play {t_sp:.1f} s, "
+                         f"train {t_tr:.1f} s, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+            verdict = self.play_vs_best_model(n_games=arena_games) if arena and self.rank == 0 else None   # :96
+            report.append({"learn_iteration": l_i, "fragments": len(mem["outcome"]), "self_play_s": t_sp, "train_s": t_tr,
+                           "loss_first": losses[0] if losses else None, "loss_last": losses[-1] if losses else None,
+                           "arena": verdict})
+        return report
+
+    # ---- play_vs_best_model / play_vs_model, alpha_versus.rs:16-81 ----
+    def play_vs_best_model(self, n_games=400):
+        from .versus import Agent, Player, play
+        mdir = os.path.join(self.root, "models", "backgammon")
+        best = os.path.join(mdir, "best_model.npy")
+        if not os.path.exists(best):
+            self.log("No best model was found, saving current model as best...")
+            os.makedirs(mdir, exist_ok=True)
+            np.save(best, self.blob)
+            return "saved-as-best"
+        other = Engine(self.engine.device)
+        other.load_weights(np.load(best))
+        res = play(Player(Agent.MODEL, self.engine), Player(Agent.MODEL, other), self.mcts_config,
+                   self.config.temperature, seed=self.seed + 77 * self.calls, num_games=n_games)
+        other.close()
+        self.log(f"Match result: {res}")
+        if res.winrate >= 0.55:                                                 # alpha_versus.rs:74-80
+            np.save(best, self.blob)
+            return "new model was better!"
+        if res.winrate <= 0.45:
+            return "current best model is still better!"
+        return "new model vs current best was inconclusive, keeping current best!"

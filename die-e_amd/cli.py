@@ -1,0 +1,128 @@
+"""die-e's command line (src/main.rs:15-216) over the HIP engine:
+
+    diee.py [-c FILE] -g {tic-tac-toe,backgammon} [-n N] learn  [-m MODEL]
+    diee.py ...                                          play   -a AGENT [-m MODEL] --agent-two AGENT [--model-path-two MODEL] -o DIR
+    diee.py ...                                          train  [-m MODEL] [-o OUT] [-r RUN [-l LRN [-s SP]]]
+    diee.py ...                                          replay -g GAME.json
+
+Same subcommands, short flags and 13 TOML keys as the reference; clap's kebab-case long flags and the
+README's snake_case spellings are both accepted.  Models and training data are .npy files (the
+reference's .ot libtorch archives need tch).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="die-e")
+    ap.add_argument("-c", "--config", metavar="FILE", default="./config")                     # main.rs:17-19,89-91
+    ap.add_argument("-g", "--game", required=True, choices=["tic-tac-toe", "backgammon"])     # :21-22,80-83
+    ap.add_argument("-n", "--n-cpus", "--n_cpus", type=int, default=None)                     # :24-26
+    sub = ap.add_subparsers(dest="command", required=True)
+    le = sub.add_parser("learn")                                                              # :35-39
+    le.add_argument("-m", "--model-path", "--model_path", default=None)
+    pl = sub.add_parser("play")                                                               # :40-56
+    pl.add_argument("-a", "--agent-one", "--agent_one", default=None)
+    pl.add_argument("-m", "--model-path-one", "--model_path_one", default=None)
+    pl.add_argument("--agent-two", "--agent_two", default=None)
+    pl.add_argument("--model-path-two", "--model_path_two", default=None)
+    pl.add_argument("-o", "--output-path", "--output_path", default=None)
+    tr = sub.add_parser("train")                                                              # :57-73
+    tr.add_argument("-m", "--model-path", "--model_path", default=None)
+    tr.add_argument("-o", "--out-path", "--out_path", default=None)
+    tr.add_argument("-r", "--run-id", "--run_id", default=None)
+    tr.add_argument("-l", "--learn", default=None)
+    tr.add_argument("-s", "--self-play", "--self_play", default=None)
+    rp = sub.add_parser("replay")                                                             # :74-78
+    rp.add_argument("-g", "--game-path", "--game_path", required=True)
+    return ap
+
+
+def training_data_path(game_name, run_id, learn, self_play, root="."):
+    """main.rs:175-182"""
+    base = os.path.join(root, "data", game_name)
+    if run_id is None and learn is None and self_play is None:
+        return base
+    if run_id is not None and learn is None and self_play is None:
+        return os.path.join(base, f"run-{run_id}")
+    if run_id is not None and learn is not None and self_play is None:
+        return os.path.join(base, f"run-{run_id}", f"lrn-{learn}")
+    if run_id is not None and learn is not None and self_play is not None:
+        return os.path.join(base, f"run-{run_id}", f"lrn-{learn}", f"sp-{self_play}")
+    raise ValueError("the request for the training data is incorrect, run die-e learn --help for more info")
+
+
+def get_all_paths_rec(d, res):
+    """main.rs:218-231: every directory whose name contains "sp" is a data directory"""
+    if os.path.isdir(d):
+        for name in sorted(os.listdir(d)):
+            p = os.path.join(d, name)
+            if "sp" in name:
+                res.append(p)
+            else:
+                get_all_paths_rec(p, res)
+    return res
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.game != "backgammon":
+        sys.exit("tic-tac-toe runs on the CPU oracle only (BASELINE config 1 is CPU plumbing); "
+                 "the HIP engine implements backgammon")
+    from . import Engine
+    from .alphazero import AlphaZero, load_config, mcts_config_from
+    from .versus import Agent, EngineRules, Player, play, print_game, save_game
+    if args.command == "replay":                                                              # main.rs:208-213
+        print_game(args.game_path, wait_user_input=sys.stdin.isatty())
+        return 0
+    conf = load_config(args.config)
+    n_cpus = os.cpu_count() or 1
+    if args.n_cpus is not None and args.n_cpus > n_cpus:                                      # main.rs:100-106
+        sys.exit(f"Value provided in n_cpus flag ({args.n_cpus}) is larger than total cpus in the device ({n_cpus})!")
+    print(f"Number of CPU's to use {args.n_cpus or n_cpus // 2}")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    eng = Engine(local_rank)
+    if args.command == "learn":                                                               # main.rs:121-124
+        az = AlphaZero.from_config(eng, conf, model_path=args.model_path, rank=int(os.environ.get("RANK", "0")),
+                                   world=int(os.environ.get("WORLD_SIZE", "1")))
+        for row in az.learn_parallel():
+            print(row)
+    elif args.command == "play":                                                              # main.rs:125-171
+        a1, a2 = Agent.parse(args.agent_one), Agent.parse(args.agent_two)
+        if args.output_path is None:
+            sys.exit("No output path given.")
+        if not os.path.isdir(args.output_path):
+            sys.exit("Output path is not a directory or does not exist!")
+
+        def model(path):
+            if path is None:
+                return None
+            e = Engine(local_rank)
+            e.load_weights(np.load(path))
+            return e
+        m1, m2 = model(args.model_path_one), model(args.model_path_two)
+        res = play(Player(a1, m1), Player(a2, m2), mcts_config_from(conf), float(conf["temperature"]),
+                   rules=EngineRules(m1 or m2 or eng))
+        print(f"{res}\n Saving games...")
+        for g in res.games:
+            save_game(g, args.output_path)
+    elif args.command == "train":                                                             # main.rs:172-207
+        print("Starting training process")
+        data_path = training_data_path("backgammon", args.run_id, args.learn, args.self_play)
+        if not os.path.exists(data_path):
+            sys.exit(f"[TRAIN] the specified path {data_path} does not exist!")
+        print(f"Loading all data under {data_path}")
+        paths = get_all_paths_rec(data_path, [])
+        mem = AlphaZero.concat([AlphaZero.load_training_data(p) for p in paths])
+        print(f"Total memory fragments: {len(mem['outcome'])}")
+        az = AlphaZero.from_config(eng, conf, model_path=args.model_path)
+        az.train(mem)
+        az.sync_engine()
+        out = args.out_path or os.path.join(".", "models", "backgammon", "trained_model.npy")
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+        np.save(out, az.blob)
+        print(f"Trained model saved successfully, saved to {out}")
+    return 0

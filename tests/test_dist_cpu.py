@@ -58,3 +58,48 @@ def test_two_rank_sharded_self_play_gloo(oracle):
     for g in range(6):
         part, gl = (a, np.array(games0)) if g < 3 else (b, np.array(games1))
         assert part[gl == g].tobytes() == full["ps"][full["game"] == g].tobytes()
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    import diee_amd
+    az = importlib.import_module("die-e_amd.alphazero")
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = orc.MctsCfg(iterations=4, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    r = orc.self_play_parallel(1, 2, cfg, 1.25, 3, orc.hash_eval_fn(), orc.game(1), first_game_id=2 * rank)
+    mem = {k: r[k][:8] for k in ("outcome", "ps", "state")}          # each rank trains on its own games
+    a = az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, 1, 8, 2), diee_amd.MctsConfig.default(4),
+                     az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0), train_device="cpu",
+                     rank=rank, world=world, quiet=True)
+    losses = a.train(mem)
+    a.sync_engine()
+    w = torch.from_numpy(a.blob.copy())
+    # BatchNorm running statistics are per-rank buffers (DDP broadcasts rank 0's at the next forward); compare parameters
+    q.put((rank, losses, float(w[:256 * 6 * 9].double().sum()), float(w[-1352 * 768 - 2500:-2500].double().sum())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_training_step_gloo():
+    """config 5's training leg: DistributedDataParallel averages the gradients, so both ranks hold the same weights"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, a0, b0), (_, l1, a1, b1) = res
+    assert np.isfinite(l0 + l1).all()
+    assert l0 != l1                    # different shards, different losses
+    assert a0 == a1 and b0 == b1       # identical parameters after the all-reduced step

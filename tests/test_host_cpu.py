@@ -1,0 +1,156 @@
+"""CPU tests of the host-side callers of the hot path: config / CLI surface,
+training step, data and game files, and the arena driver running on the oracle backends."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import diee_amd
+
+az = importlib.import_module("die-e_amd.alphazero")
+cli = importlib.import_module("die-e_amd.cli")
+versus = importlib.import_module("die-e_amd.versus")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_has_the_references_13_keys():
+    conf = az.load_config(os.path.join(ROOT, "config-example.toml"))
+    assert set(az.CONFIG_KEYS) <= set(conf) and len(az.CONFIG_KEYS) == 13
+    c = az.AlphaZeroConfig.from_config(conf)
+    assert (c.temperature, c.num_self_play_batches, c.training_batch_size) == (1.25, 1024, 256)   # config-example.toml:2-7
+    m = az.mcts_config_from(conf)
+    assert (m.iterations, m.c, m.round_limit) == (100, 2.0, 400) and abs(m.dir_alpha - 0.3) < 1e-7
+    o = az.OptimizerParams.from_config(conf)
+    assert (o.wd, o.lr) == (0.0001, 0.001)
+
+
+def test_missing_config_key_is_an_error(tmp_path):
+    p = tmp_path / "c.toml"
+    p.write_text("temperature = 1.0\n")
+    with pytest.raises(KeyError):
+        az.load_config(str(p))
+
+
+def test_cli_surface_matches_main_rs():
+    P = cli.build_parser()
+    a = P.parse_args(["-c", "cfg", "-g", "backgammon", "-n", "4", "learn", "-m", "m.npy"])
+    assert (a.config, a.game, a.n_cpus, a.command, a.model_path) == ("cfg", "backgammon", 4, "learn", "m.npy")
+    a = P.parse_args(["-g", "backgammon", "play", "-a", "Model", "-m", "a", "--agent-two", "random", "--model-path-two", "b", "-o", "out"])
+    assert (a.agent_one, a.model_path_one, a.agent_two, a.model_path_two, a.output_path) == ("Model", "a", "random", "b", "out")
+    a = P.parse_args(["-g", "backgammon", "play", "--agent_one", "mcts", "--agent_two", "model", "--output_path", "o"])   # README spelling
+    assert (a.agent_one, a.agent_two, a.output_path) == ("mcts", "model", "o")
+    a = P.parse_args(["-g", "tic-tac-toe", "train", "-m", "m", "-o", "out", "-r", "R", "-l", "1", "-s", "2"])
+    assert (a.game, a.run_id, a.learn, a.self_play, a.out_path) == ("tic-tac-toe", "R", "1", "2", "out")
+    a = P.parse_args(["-g", "backgammon", "replay", "-g", "game.json"])
+    assert a.command == "replay" and a.game_path == "game.json"
+    assert P.parse_args(["-g", "backgammon", "learn"]).config == "./config"      # main.rs:89-91
+    with pytest.raises(SystemExit):
+        P.parse_args(["learn"])                                                   # -g is required
+    assert versus.Agent.parse("MODEL") == versus.Agent.MODEL and versus.Agent.parse("random") == versus.Agent.RANDOM
+    with pytest.raises(ValueError):
+        versus.Agent.parse("human")
+
+
+def test_training_data_path_rules(tmp_path):
+    f = cli.training_data_path
+    assert f("backgammon", None, None, None) == os.path.join(".", "data", "backgammon")          # main.rs:177
+    assert f("backgammon", "X", None, None).endswith(os.path.join("backgammon", "run-X"))
+    assert f("backgammon", "X", "1", None).endswith(os.path.join("run-X", "lrn-1"))
+    assert f("backgammon", "X", "1", "2").endswith(os.path.join("run-X", "lrn-1", "sp-2"))
+    for bad in ((None, "1", None), (None, None, "2"), ("X", None, "2")):
+        with pytest.raises(ValueError):
+            f("backgammon", *bad)
+    for d in ("run-a/lrn-0/sp-0", "run-a/lrn-0/sp-1", "run-a/lrn-1/sp-0", "run-b/lrn-0/sp-0"):
+        os.makedirs(tmp_path / d)
+    got = cli.get_all_paths_rec(str(tmp_path), [])
+    assert len(got) == 4 and all("sp-" in g for g in got)                         # main.rs:218-231
+
+
+def small_memory(oracle, n_games=3, iters=4):
+    cfg = oracle.MctsCfg(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    r = oracle.self_play_parallel(1, n_games, cfg, 1.25, 3, oracle.hash_eval_fn(), oracle.game(1))
+    return {"outcome": r["outcome"], "ps": r["ps"], "state": r["state"]}
+
+
+def test_training_data_round_trip(oracle, tmp_path):
+    mem = small_memory(oracle)
+    az.AlphaZero.save_training_data(mem, str(tmp_path))
+    back = az.AlphaZero.load_training_data(str(tmp_path))
+    for k in mem:
+        assert (back[k] == mem[k]).all()
+    assert np.load(tmp_path / "states.npy").shape[1:] == (6, 4, 6)               # states.ot [M,6,4,6], alphazero.rs:164
+    with pytest.raises(FileNotFoundError):
+        az.AlphaZero.save_training_data(mem, str(tmp_path / "missing"))          # alphazero.rs:150-152
+
+
+def test_torch_resnet_matches_the_blob_layout_and_trains(oracle):
+    import torch
+    from oracle import nn_ref
+    torch.manual_seed(0)
+    blob = diee_amd.random_weights(0)
+    net = az.make_resnet().load_blob(blob)
+    assert (net.to_blob() == blob).all()                                         # exact round trip of the diee.h layout
+    mem = small_memory(oracle)
+    x = mem["state"][:6]
+    net.eval()
+    with torch.no_grad():
+        logits, value = net.forward_train(torch.from_numpy(x).reshape(-1, 6, 4, 6))
+    rp, rv, rl = nn_ref.forward_t(nn_ref.parse(blob), x)
+    assert np.allclose(logits.numpy(), rl, atol=1e-5) and np.allclose(value[:, 0].numpy(), rv, atol=1e-6)
+    # train(): soft-label CE on un-renormalised ps + MSE, Adam with L2 (alphazero.rs:202-261)
+    conf = az.AlphaZeroConfig(1.25, 1, 1, 1, 8, 3)
+    a = az.AlphaZero(None, conf, diee_amd.MctsConfig.default(4), az.OptimizerParams(1e-4, 1e-3), blob=blob,
+                     train_device="cpu", quiet=True)
+    sub = {k: v[:16] for k, v in mem.items()}
+    l1 = a.train(sub)
+    l2 = a.train(sub)
+    assert len(l1) == 2 and np.isfinite(l1 + l2).all()
+    assert np.mean(l2) < np.mean(l1)                                             # the step descends on its own batch
+    a.sync_engine()
+    assert np.isfinite(a.blob).all() and (a.blob != blob).any()
+    # BatchNorm ran in train mode: running statistics moved (init block mean was 0, var 1)
+    o = 256 * 6 * 9 + 256
+    assert (a.blob[o + 512:o + 768] != 0).any() and (a.blob[o + 768:o + 1024] != 1).any()
+
+
+def test_game_json_and_replay(tmp_path):
+    st = versus.new_states(1)[0]
+    st["roll"] = (3, 5)
+    g = versus.Game(versus.Agent.MODEL, versus.Agent.RANDOM, st, 7)
+    path = versus.save_game(g, str(tmp_path))
+    doc = json.load(open(path))
+    assert set(doc) == {"id", "player1", "player2", "turns", "winner", "initial_state"}        # versus.rs:27-35
+    assert doc["initial_state"]["board"][0] == versus.START and doc["initial_state"]["roll"] == [3, 5]
+    assert doc["initial_state"]["player"] == -1 and doc["turns"] == [] and doc["winner"] == "None"
+    lines = []
+    versus.print_game(path, out=lines.append)
+    txt = "\n".join(lines)
+    assert "Player 1: Model, Player 2: Random" in txt and "Current turn: Player 1" in txt and "Roll: (3, 5)" in txt
+
+
+def test_arena_driver_on_the_oracle_backends(oracle):
+    """play() (versus.rs:160-268) with Random agents and with Model agents searching on the oracle"""
+    from oracle.arena_backend import OracleRules, OracleSearch
+    rules = OracleRules()
+    P = versus.Player
+    res = versus.play(P(versus.Agent.RANDOM), P(versus.Agent.RANDOM), diee_amd.MctsConfig.default(4), 1.25, seed=5,
+                      num_games=10, round_limit=400, rules=rules)
+    assert res.wins_p1 + res.wins_p2 + res.draws == 10 and res.n_games == 10 and len(res.games) == 10
+    assert abs(res.winrate - res.wins_p1 / 10) < 1e-12
+    assert sorted(g.initial_state["id"] for g in res.games) == list(range(10))
+    assert [g.initial_state["player"] for g in sorted(res.games, key=lambda g: g.initial_state["id"])] == [-1] * 5 + [1] * 5
+    off = res.final_states["off"]
+    assert ((off[:, 0] == 15) | (off[:, 1] == 15)).all()                         # random games end with a winner
+    # a low round limit turns unfinished games into draws (versus.rs:233-237)
+    res2 = versus.play(P(versus.Agent.RANDOM), P(versus.Agent.RANDOM), diee_amd.MctsConfig.default(4), 1.25, seed=5,
+                       num_games=6, round_limit=5, rules=rules)
+    assert res2.draws == 6 and res2.rounds == 5
+    # Model vs Random with the oracle search (hash evaluator)
+    srch = OracleSearch(oracle.hash_eval_fn(), oracle.game(1))
+    res3 = versus.play(P(versus.Agent.MODEL), P(versus.Agent.RANDOM), diee_amd.MctsConfig.default(6), 1.25, seed=9,
+                       num_games=4, round_limit=400, rules=rules, search1=srch)
+    assert res3.wins_p1 + res3.wins_p2 == 4
+    with pytest.raises(NotImplementedError):
+        versus.play(P(versus.Agent.MCTS), P(versus.Agent.RANDOM), diee_amd.MctsConfig.default(4), 1.25, num_games=2, rules=rules)

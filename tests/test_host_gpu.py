@@ -1,0 +1,65 @@
+"""GPU tests of the host-side callers: the arena on the engine equals the arena on
+the oracle backends bit for bit, and one learn iteration (self-play on the engine -> PyTorch-ROCm training ->
+weights folded back into the engine) leaves the engine consistent with the trained network."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+az = importlib.import_module("die-e_amd.alphazero")
+versus = importlib.import_module("die-e_amd.versus")
+
+
+def test_arena_engine_equals_oracle(oracle):
+    import diee_amd
+    from oracle.arena_backend import OracleRules, OracleSearch
+    e1 = diee_amd.Engine(0); e1.load_weights(diee_amd.random_weights(0))
+    e2 = diee_amd.Engine(0); e2.load_weights(diee_amd.random_weights(1))
+    cfg = diee_amd.MctsConfig(iterations=6, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    P = versus.Player
+    res = versus.play(P(versus.Agent.MODEL, e1), P(versus.Agent.MODEL, e2), cfg, 1.25, seed=21, num_games=8, round_limit=60)
+
+    def ev(e):
+        return oracle.make_eval(lambda st: e.forward_t(st.view(oracle.BG_STATE).reshape(-1)), 1352)
+    f1, f2 = ev(e1), ev(e2)
+    ref = versus.play(P(versus.Agent.MODEL), P(versus.Agent.MODEL), cfg, 1.25, seed=21, num_games=8, round_limit=60,
+                      rules=OracleRules(), search1=OracleSearch(f1), search2=OracleSearch(f2))
+    assert res.final_states.tobytes() == ref.final_states.tobytes()
+    assert (res.wins_p1, res.wins_p2, res.draws, res.rounds) == (ref.wins_p1, ref.wins_p2, ref.draws, ref.rounds)
+    assert sorted((g.initial_state["id"], g.winner) for g in res.games) == sorted((g.initial_state["id"], g.winner) for g in ref.games)
+    # Model vs Random on the engine
+    r2 = versus.play(P(versus.Agent.MODEL, e1), P(versus.Agent.RANDOM), cfg, 1.25, seed=4, num_games=6, round_limit=400)
+    assert r2.wins_p1 + r2.wins_p2 == 6
+    e1.close(); e2.close()
+
+
+def test_learn_iteration_smoke(oracle, tmp_path):
+    import torch
+    import diee_amd
+    from oracle import nn_ref
+    eng = diee_amd.Engine(0)
+    conf = az.AlphaZeroConfig(temperature=1.25, learn_iterations=1, self_play_iterations=2, num_epochs=1,
+                              training_batch_size=64, num_self_play_batches=8)
+    a = az.AlphaZero(eng, conf, diee_amd.MctsConfig(iterations=6, c=2.0, round_limit=80, dir_alpha=0.3, dir_eps=0.25),
+                     az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0), root=str(tmp_path), quiet=True)
+    assert a.device == "cuda"
+    rep = a.learn_parallel(arena=True, arena_games=4)
+    assert len(rep) == 1 and rep[0]["fragments"] > 0 and np.isfinite(rep[0]["loss_last"])
+    assert rep[0]["arena"] == "saved-as-best"                                    # alpha_versus.rs:19-27
+    run = next((tmp_path / "data" / "backgammon").iterdir())
+    sp0 = az.AlphaZero.load_training_data(str(run / "lrn-0" / "sp-0")); sp1 = az.AlphaZero.load_training_data(str(run / "lrn-0" / "sp-1"))
+    assert len(sp1["outcome"]) > len(sp0["outcome"])                             # cumulative memory per sp dir (Q20)
+    assert (tmp_path / "models" / "backgammon" / "model_0.npy").exists() and (tmp_path / "models" / "backgammon" / "best_model.npy").exists()
+    # the engine now runs the trained weights: compare with the fp32 restatement on the same blob
+    states = oracle.random_walk_states(8, 2)[:24]
+    pol, val = eng.forward_t(states)
+    rp, rv, _ = nn_ref.forward_t(nn_ref.parse(a.blob), oracle.planes_batch(states))
+    assert np.abs(pol - rp).max() <= 2e-3 and np.abs(val - rv).max() <= 1e-2
+    assert (a.blob != diee_amd.random_weights(0)).any()
+    # second learn iteration plays the arena against the saved best model
+    verdict = a.play_vs_best_model(n_games=4)
+    assert verdict in ("new model was better!", "current best model is still better!",
+                       "new model vs current best was inconclusive, keeping current best!")
+    eng.close()
