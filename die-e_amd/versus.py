@@ -90,17 +90,15 @@ def check_winner(states):                      # backgammon_logic.rs:527-534 (pl
 
 
 def weighted_select(row, u01):                 # alphazero.rs:129-137 (rand WeightedIndex over f64 weights)
-    total = 0.0
-    for a in range(len(row)):
-        total += float(row[a])
-    x, cum, last_nz = u01 * total, 0.0, 0
-    for a in range(len(row)):
-        if row[a] != 0.0:
-            last_nz = a
-        cum += float(row[a])
-        if cum > x:
-            return a
-    return last_nz
+    """cumulative weights in index order (sequential f64 sums, like the device code), u ~ U[0,total), first
+    index whose cumulative weight exceeds u"""
+    cum = np.cumsum(row.astype(np.float64))    # np.cumsum is a sequential running sum
+    x = u01 * cum[-1]
+    hit = np.nonzero(cum > x)[0]
+    if len(hit):
+        return int(hit[0])
+    nz = np.nonzero(row)[0]
+    return int(nz[-1]) if len(nz) else 0
 
 
 class Game:                                    # versus.rs:27-52
@@ -197,14 +195,14 @@ def get_actions_for_player(player, states, ids, rnd, mcts_config, temp, seed, ru
                                  np.full(n, rnd, dtype=np.uint32))
         inv_t = np.float32(1.0 / float(temp))
         codes = np.full(n, 1351, dtype=np.uint32)
+        ri, ci = np.nonzero(np.nan_to_num(probs) > 0)
+        powed = np.zeros((n, BG_ACTIONS), dtype=np.float32)
+        if len(ri):
+            powed[ri, ci] = rules.powf(probs[ri, ci].astype(np.float32), inv_t)  # .pow_(1.0 / temp), :283 (one batched call)
         for i in range(n):
             if nch[i] == 0:                    # :292 root.children.is_empty() -> EMPTY_MOVE
                 continue
-            row = probs[i]
-            nz = np.nonzero(row)[0]
-            powed = np.zeros(BG_ACTIONS, dtype=np.float32)
-            powed[nz] = rules.powf(row[nz].astype(np.float32), inv_t)            # .pow_(1.0 / temp), :283
-            codes[i] = weighted_select(powed, float(uni[i]))
+            codes[i] = weighted_select(powed[i], float(uni[i]))
         return rules.decode(states, codes)     # :301
     if player.player_type == Agent.RANDOM:     # :308-317
         vm, cnt = rules.valid_moves(states)
