@@ -139,10 +139,10 @@ def main():
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
                     "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"])}
         # the tower of 38 3x3 convs is ~95 % of the GPU time; it runs as ONE fused launch (k_tower) while more
-        # than 272 games are alive and as 38 per-layer launches (k_conv3x3_sk) below that
-        r_fused = roof("k_tower (38 fused 3x3 conv layers, one launch; batches > 272 boards)",
-                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower"))
-        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; batches <= 272 boards)",
+        # than 200 games are alive and as 38 per-layer launches (k_conv3x3_sk) below that
+        r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 200 boards)",
+                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16") or pmc_traffic("diee::k_tower"))
+        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; batches <= 200 boards)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         dominant, other = (r_fused, r_layer) if tot["tower_seconds"] >= tot["conv_seconds"] else (r_layer, r_fused)
         out = {

@@ -79,6 +79,10 @@ class Fragments(C.Structure):
 
 
 _lib = None
+_TORCH_LOADED_FIRST = False     # PyTorch bundles its own ROCm runtime libraries.  Whichever side is loaded first
+                                # provides them to the whole process (same sonames): if torch came first both torch.cuda
+                                # and the engine work; if libdiee.so came first the engine works and torch.cuda must
+                                # not be touched.  Processes that need both import torch first (alphazero.py, bench.py).
 
 
 def load_library(path=None):
@@ -86,6 +90,9 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    global _TORCH_LOADED_FIRST
+    import sys
+    _TORCH_LOADED_FIRST = "torch" in sys.modules
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise ImportError(f"{p} is missing: build it with `python die-e_amd/build.py` "
@@ -143,9 +150,9 @@ class Engine:
 
     def __init__(self, device=0, game_id=GAME_BACKGAMMON):
         import sys
-        if "torch" in sys.modules:          # see alphazero.py: torch's bundled HIP runtime must initialise first
-            sys.modules["torch"].cuda.is_available()
         self._L = load_library()
+        if _TORCH_LOADED_FIRST:             # torch's runtime serves the process: let it initialise before the engine does
+            sys.modules["torch"].cuda.is_available()
         h = C.c_void_p()
         st = self._L.diee_create(device, game_id, C.byref(h))
         if st != OK:

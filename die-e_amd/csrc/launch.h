@@ -23,7 +23,8 @@ void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geome
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
                     const uint16_t* res, uint16_t* out, float* out_v, int G, int N);
-void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G);
+void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
+                  uint16_t* x_out, int G);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);

@@ -75,6 +75,21 @@ void pack_conv(const std::vector<float>& w, int cout, int cin, int n_pad, int ci
                     }
 }
 
+// 16-column B fragments for v_mfma_f32_16x16x32_bf16:
+//   [n/16][kstep = cs32*9 + tap][lane][j]:  n = nf*16 + (lane&15),  c = cs32*32 + 8*(lane>>4) + j
+void pack_conv16(const std::vector<float>& w, int cout, int cin, std::vector<uint16_t>& out) {
+    const int csteps = cin / 32, ksteps = csteps * 9, nfr = cout / 16;
+    out.assign((size_t)nfr * ksteps * 64 * 8, 0);
+    for (int s = 0; s < nfr; ++s)
+        for (int cs = 0; cs < csteps; ++cs)
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = s * 16 + (lane & 15), c = cs * 32 + 8 * (lane >> 4) + j;
+                        out[(((size_t)s * ksteps + cs * 9 + t) * 64 + lane) * 8 + j] = f2bf_host(w[((size_t)n * cin + c) * 9 + t]);
+                    }
+}
+
 }  // namespace
 
 size_t weights_count_bg() { return layout().total; }
@@ -115,13 +130,24 @@ void Engine::load_weights(const float* blob, size_t n) {
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
-    if (const char* v = getenv("DIEE_FUSED_MIN_GAMES")) net->fused_min_games = atoi(v);   // development / tests
-    if (const char* v = getenv("DIEE_FUSED2_MIN_GAMES")) net->fused2_min_games = atoi(v);
+    if (const char* v = getenv("DIEE_TOWER_TABLE")) {      // development / tests
+        net->tower_table.clear();
+        std::string t(v);
+        size_t pos = 0;
+        while (pos < t.size() && t != "none") {
+            const size_t c = t.find(':', pos), e2 = t.find(',', pos);
+            if (c == std::string::npos) break;
+            net->tower_table.push_back({atoi(t.substr(pos, c - pos).c_str()), atoi(t.substr(c + 1, (e2 == std::string::npos ? t.size() : e2) - c - 1).c_str())});
+            if (e2 == std::string::npos) break;
+            pos = e2 + 1;
+        }
+    }
     NetWeights& W = *net;
     std::vector<float> w, b;
     std::vector<uint16_t> pk;
     W.wtower.ensure((size_t)38 * 8 * 144 * 64 * 8);
     W.btower.ensure((size_t)38 * 256);
+    W.wtower16.ensure((size_t)38 * 16 * 72 * 64 * 8);
     auto up_conv = [&](int layer, const ConvOff& c, const BnOff& bn, int n_pad, int cin_pad) {
         fold(blob, c, bn, w, b);
         pack_conv(w, c.cout, c.cin, n_pad, cin_pad, pk);
@@ -130,6 +156,9 @@ void Engine::load_weights(const float* blob, size_t n) {
         if (layer >= 1 && layer <= 38) {
             h2d(W.wl(layer), pk.data(), pk.size());
             h2d(W.bl(layer), bp.data(), (size_t)n_pad);
+            sync();
+            pack_conv16(w, c.cout, c.cin, pk);
+            h2d(W.wtower16.p + (size_t)(layer - 1) * 16 * 72 * 64 * 8, pk.data(), pk.size());
         } else {
             W.wconv[layer].ensure(pk.size());
             h2d(W.wconv[layer].p, pk.data(), pk.size());
@@ -199,10 +228,9 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
-    if (G > W.fused_min_games) {
-        launch_tower(st, 0, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);       // all 38 layers, activations stay in LDS
-    } else if (G > W.fused2_min_games) {
-        launch_tower(st, 1, W.actX.p, W.wtower.p, W.btower.p, W.actX.p, G);
+    const int tgeom = W.tower_geometry_for(G);
+    if (tgeom >= 0) {
+        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
     } else {
         for (int i = 0; i < BLOCKS; ++i) {
             launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
@@ -212,7 +240,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     }
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        const bool fused = G > W.fused_min_games || G > W.fused2_min_games;
+        const bool fused = tgeom >= 0;
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, fused ? 1 : 38, fused});
     }
     launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
@@ -275,14 +303,14 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     e.tmp_a.ensure((size_t)G * 32); e.tmp_b.ensure((size_t)G * 1352 * 4); e.tmp_c.ensure((size_t)G * 4);
     HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
     const int se = W.sample_every; W.sample_every = 0;
-    const int fm = W.fused_min_games, fm2 = W.fused2_min_games;
-    W.fused_min_games = variant == 100 ? 0 : (variant == 0 ? fm : 1 << 30);
-    W.fused2_min_games = variant == 101 ? 0 : (variant == 0 ? fm2 : 1 << 30);
+    const auto saved_table = W.tower_table;
+    if (variant >= 100 && variant <= 105) W.tower_table = {{0, variant - 100}};
+    else if (variant != 0) W.tower_table.clear();
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
         nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
     }
-    W.sample_every = se; W.fused_min_games = fm; W.fused2_min_games = fm2;
+    W.sample_every = se; W.tower_table = saved_table;
     HIPCHK(hipEventRecord(b, st));
     HIPCHK(hipEventSynchronize(b));
     HIPCHK(hipEventElapsedTime(&ms, a, b));

@@ -10,11 +10,19 @@ struct NetWeights {
     DevBuf<uint16_t> wconv[40];     // packed bf16 B fragments: 0 init, 39 heads (1..38 live in wtower)
     DevBuf<float> bconv[40];        // folded bias (1..38 live in btower)
     DevBuf<uint16_t> wtower;        // [38][8][144][64][8] bf16: the tower layers, contiguous (fused tower kernel)
+    DevBuf<uint16_t> wtower16;      // [38][16][72][64][8] bf16: the same weights as 16-column fragments (16x16x32 MFMA)
     DevBuf<float> btower;           // [38][256]
     uint16_t* wl(int layer) { return (layer >= 1 && layer <= 38) ? wtower.p + (size_t)(layer - 1) * 8 * 144 * 64 * 8 : wconv[layer].p; }
     float* bl(int layer) { return (layer >= 1 && layer <= 38) ? btower.p + (size_t)(layer - 1) * 256 : bconv[layer].p; }
-    int fused_min_games = 560;      // batches above this run the tower as one launch (4 boards per workgroup)
-    int fused2_min_games = 272;     // batches above this (and <= fused_min_games): one launch, 2 boards per workgroup
+    // fused-tower dispatch: the first entry with G > min_games wins; batches below every entry run per-layer kernels.
+    // Measured on MI355X (scripts/fwd_sweep*.py): 16x16x32 MFMA with 4 boards per workgroup above 768 boards,
+    // 3 boards above 512, 2 boards above 200.  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
+    struct TowerRule { int min_games, geometry; };
+    std::vector<TowerRule> tower_table = {{768, 5}, {512, 4}, {200, 3}};
+    int tower_geometry_for(int G) const {
+        for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
+        return -1;
+    }
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias
     bool loaded = false;

@@ -94,19 +94,18 @@ def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(21, 12)[:700]
     assert len(states) == 700
-    monkeypatch.setenv("DIEE_FUSED_MIN_GAMES", "0")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:0")
     e1 = diee_amd.Engine(0); e1.load_weights(blob)
     p1, v1 = e1.forward_t(states)                 # fused (700 > 0)
     p1s, v1s = e1.forward_t(states[:5])           # fused, ragged small batch (5 boards: padded workgroup)
-    monkeypatch.setenv("DIEE_FUSED_MIN_GAMES", "1000000")
-    monkeypatch.setenv("DIEE_FUSED2_MIN_GAMES", "0")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:1")
     e3 = diee_amd.Engine(0); e3.load_weights(blob)
     p3, v3 = e3.forward_t(states)                 # fused, 2 boards per workgroup (mid-size batches)
     assert (p1 == p3).all() and (v1 == v3).all()
     p3s, v3s = e3.forward_t(states[:5])
     assert (p3s == p1s).all() and (v3s == v1s).all()
     e3.close()
-    monkeypatch.setenv("DIEE_FUSED2_MIN_GAMES", "1000000")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "none")
     e2 = diee_amd.Engine(0); e2.load_weights(blob)
     p2, v2 = e2.forward_t(states)                 # per-layer kernels, 4 boards x 128 channels
     assert (p1 == p2).all() and (v1 == v2).all()
@@ -114,3 +113,27 @@ def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
     assert np.abs(p1[:40] - rp).max() <= POLICY_ATOL and np.abs(v1[:40] - rv).max() <= VALUE_ATOL
     assert np.abs(p1s - rp[:5]).max() <= POLICY_ATOL and np.abs(v1s - rv[:5]).max() <= VALUE_ATOL
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("geom", [3, 4, 5])
+def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
+    """the fused tower on v_mfma_f32_16x16x32_bf16 (2 / 3 / 4 boards per workgroup): same network, different
+    MFMA shape, so equal to the 32x32x16 kernels up to fp32 summation order, and within the stated tolerance of fp32"""
+    import diee_amd
+    from oracle.nn_ref import parse, forward_t
+    blob = diee_amd.random_weights(0)
+    states = oracle.random_walk_states(33, 4)[:301]          # ragged: not a multiple of 2, 3 or 4 boards
+    monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
+    e = diee_amd.Engine(0); e.load_weights(blob)
+    p, v = e.forward_t(states)
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:0")
+    e0 = diee_amd.Engine(0); e0.load_weights(blob)
+    p0, v0 = e0.forward_t(states)
+    assert np.abs(p - p0).max() < 2e-5 and np.abs(v - v0).max() < 5e-3
+    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:32]))
+    assert np.abs(p[:32] - rp).max() <= POLICY_ATOL and np.abs(v[:32] - rv).max() <= VALUE_ATOL
+    assert (np.abs(p[:32] - rp) / rp).max() < 0.08
+    # row independence within the geometry
+    p2, v2 = e.forward_t(states[::-1].copy())
+    assert (p2[::-1] == p).all() and (v2[::-1] == v).all()
+    e.close(); e0.close()
