@@ -513,27 +513,34 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int q = 0; q < NFR; ++q)
-                    acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][f], b[q], acc[f][q], 0, 0, 0);
+                    acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);   // D = W^T x act^T
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // epilogue: C/D layout of the 16x16 shapes: col = lane&15, row = (lane>>4)*4 + i
+    // epilogue.  The operands are swapped (weights as the MFMA's A, activations as its B), so in the 16x16 C/D
+    // layout (col = lane&15, row = (lane>>4)*4 + i) a lane holds FOUR CONSECUTIVE CHANNELS of one board position:
+    // one 8-byte LDS write (and residual read) per tile instead of four 2-byte ones.
 #pragma unroll
     for (int q = 0; q < NFR; ++q) {
-        const int n = (wave * NFR + q) * 16 + (lane & 15);
-        const float bv = bias[n];
+        const int n0 = (wave * NFR + q) * 16 + (lane >> 4) * 4;
+        const float4 bv = *(const float4*)(bias + n0);
 #pragma unroll
-        for (int f = 0; f < MF; ++f)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * f + (lane >> 4) * 4 + i;
-                if (ROWS % 16 != 0 && r >= ROWS) continue;
-                const int off = r * 528 + n * 2;
-                float v = acc[f][q][i] + bv;
-                if (RES) v += bf2f(*(const uint16_t*)(tout + off));
-                v = v > 0.0f ? v : 0.0f;
-                *(uint16_t*)(tout + off) = f2bf(v);
+        for (int f = 0; f < MF; ++f) {
+            const int r = 16 * f + (lane & 15);
+            if (ROWS % 16 != 0 && r >= ROWS) continue;
+            const int off = r * 528 + n0 * 2;
+            float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
+            if (RES) {                                            // y = relu(conv2(h) + x), in place over x
+                const uint2 rv = *(const uint2*)(tout + off);
+                v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
+                v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
             }
+            v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
+            uint2 o;
+            o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+            o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+            *(uint2*)(tout + off) = o;
+        }
     }
     __syncthreads();
 }
