@@ -32,7 +32,8 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 // mcts_kernels.hip
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks);
-void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P);
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P,
+                   uint32_t next_it, float c);   // next_it: iteration to select for afterwards, kNoNextIteration = none
 void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n);
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits);
 void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed);
@@ -41,5 +42,6 @@ void launch_play_move(hipStream_t st, const Tree& T, const Games& G, uint32_t n_
 void launch_compact_live(hipStream_t st, const Games& G, uint32_t n_live, uint32_t* n_live_out);
 void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes);
 constexpr uint32_t kRootIteration = 0xFFFFFFFFu;
+constexpr uint32_t kNoNextIteration = 0xFFFFFFFEu;
 
 }  // namespace diee

@@ -68,10 +68,8 @@ __device__ __forceinline__ Best better(Best a, Best b) {      // later index win
 
 // alpha_select_leaf_node / select_alpha (alpha_mcts.rs:14-33) with alpha_ucb (node.rs:98-112):
 //   q + (c * (sqrt(N_parent) / (n + 1))) * p, f32, in this association; NaN compares Equal.
-__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
-    const uint32_t slot = blockIdx.x;
-    if (slot >= n) return;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, uint32_t slot, int lane, uint32_t it, float c,
+                                            uint32_t quirks) {
     const size_t base = (size_t)slot * T.node_cap;
     uint32_t node = 0, depth = 0;
     for (;;) {
@@ -143,6 +141,12 @@ __global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint
     }
 }
 
+__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    select_slot(T, S, slot, (int)threadIdx.x, it, c, quirks);
+}
+
 // ---- expansion + backpropagation ---------------------------------------------------------------
 struct ExpandScratch {
     WaveScratch ws;
@@ -154,7 +158,11 @@ struct ExpandScratch {
 // turn_policy_to_probs_tensor (utils.rs:74-84; root: utils.rs:60-72 on the Dirichlet-mixed policy,
 // noise.rs:27-34) + alpha_expand_tensor (node.rs:157-174).  it == kRootIt expands the roots.
 constexpr uint32_t kRootIt = 0xFFFFFFFFu;
-__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint32_t it, SearchParams P) {
+// After the expansion the same wave immediately selects this game's leaf for iteration `next_it` (kNoNext = none):
+// one MCTS kernel per network evaluation instead of two.
+constexpr uint32_t kNoNext = 0xFFFFFFFEu;
+__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint32_t it, SearchParams P, uint32_t next_it,
+                                               float c) {
     __shared__ ExpandScratch sc;
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
     const size_t base = (size_t)slot * T.node_cap;
     const bool root = it == kRootIt;
     const bool quirks = P.quirks != 0;
-    if (!root && S.iter_flags[2 * it] == 0) return;        // alpha_mcts.rs:170-172 `continue`
+    const bool active = root || S.iter_flags[2 * it] != 0;  // alpha_mcts.rs:170-172 `continue`
+    if (active) {
     if (slot == 0 && lane == 0) atomicAdd(&S.counters[CNT_NN_EVALS], (unsigned long long)n);
 
     uint32_t node = 0;
@@ -247,6 +256,11 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             const float rv = S.root_value0[0];
             for (uint32_t i = 0; i < cnt; ++i) { T.visits[base] += 1.0f; T.value[base] += rv; }
         }
+    }
+    }   // active
+    if (next_it != kNoNext) {
+        __syncthreads();                                    // lane 0's tree updates are visible to the whole wave
+        select_slot(T, S, slot, lane, next_it, c, P.quirks);
     }
 }
 
@@ -464,8 +478,9 @@ void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
     hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, n, it, c, quirks);
 }
-void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P) {
-    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, n, it, P);
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P,
+                   uint32_t next_it, float c) {
+    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, n, it, P, next_it, c);
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(256), 0, st, S, n);

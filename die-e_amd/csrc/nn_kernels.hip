@@ -622,11 +622,21 @@ __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ h
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll 8
-    for (int ks = 0; ks < 48; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(ap + ks * 16);
-        const bf16x8 b = __builtin_bit_cast(bf16x8, wp[ks * 64]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    // the layer is latency-bound (48 dependent-free k-steps, operands straight from L2): request 24 k-steps of
+    // both operands up front, then issue their MFMAs, twice
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        bf16x8 av[24];
+        u32x4 bvq[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            av[i] = *(const bf16x8*)(ap + (half * 24 + i) * 16);
+            bvq[i] = wp[(half * 24 + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep all 48 loads ahead of the first MFMA
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bvq[i]), acc, 0, 0, 0);
     }
     const int n = nslice * 32 + (lane & 31);
     if (n >= 1352) return;

@@ -134,11 +134,11 @@ void mcts_run(Engine& e, uint32_t n, const diee_mcts_cfg& cfg, uint64_t seed, ui
     launch_init_roots(st, T, S, n);
     nn_forward(e, B.eval_states.p, (int)n, B.policy.p, B.nn_value.p);  // forward_policy, alpha_mcts.rs:104
     const SearchParams P{seed, cfg.dir_eps, quirks};
-    launch_expand(st, T, S, n, kRootIteration, P);
+    // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
+    launch_expand(st, T, S, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
-        launch_select(st, T, S, n, it, cfg.c, quirks);
         nn_forward(e, B.eval_states.p, (int)n, B.policy.p, B.nn_value.p);   // alpha_mcts.rs:186
-        launch_expand(st, T, S, n, it, P);
+        launch_expand(st, T, S, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
     }
     launch_reduce_counters(st, S, n);
     HIPCHK(hipGetLastError());
