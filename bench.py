@@ -125,7 +125,10 @@ def main():
             # (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), at 1024 boards
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                return doc["kernels"][name]["hbm_side_bytes_per_launch_corrected"]
+                for k, v in doc["kernels"].items():
+                    if k.startswith(name) and "hbm_side_bytes_per_launch_corrected" in v:
+                        return v["hbm_side_bytes_per_launch_corrected"]
+                return None
             except Exception:
                 return None
 
@@ -141,7 +144,7 @@ def main():
         # the tower of 38 3x3 convs is ~95 % of the GPU time; it runs as ONE fused launch (k_tower) while more
         # than 200 games are alive and as 38 per-layer launches (k_conv3x3_sk) below that
         r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 200 boards)",
-                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16") or pmc_traffic("diee::k_tower"))
+                       tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; batches <= 200 boards)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         dominant, other = (r_fused, r_layer) if tot["tower_seconds"] >= tot["conv_seconds"] else (r_layer, r_fused)
