@@ -1,0 +1,71 @@
+"""GPU tests of the boundary's error behaviour and edge sizes: the reference panics (assert!/unwrap); the C ABI
+returns status codes and never truncates silently."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_inputs_are_no_ops(oracle):
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    s0 = np.zeros(0, dtype=diee_amd.BG_STATE)
+    p, c = e.get_valid_moves(s0)
+    assert p.shape == (0, 256, 4) and c.shape == (0,)
+    assert e.encode(s0, np.zeros((0, 4), np.int8)).shape == (0,)
+    assert e.decode(s0, np.zeros(0, np.uint32)).shape == (0, 4)
+    assert e.as_tensor(s0).shape == (0, 144)
+    pol, val = e.forward_t(s0)
+    assert pol.shape == (0, 1352) and val.shape == (0,)
+    r = e.alpha_mcts_parallel(s0, diee_amd.MctsConfig.default(4))
+    assert r["probs"].shape == (0, 1352)
+    e.close()
+
+
+def test_status_codes_instead_of_panics(oracle, monkeypatch):
+    import diee_amd
+    e = diee_amd.Engine(0)
+    roots = oracle.random_walk_states(1, 1)[:4]
+    cfg = diee_amd.MctsConfig.default(4)
+    with pytest.raises(diee_amd.DieeError) as ei:               # no weights yet
+        e.alpha_mcts_parallel(roots, cfg)
+    assert ei.value.status == diee_amd.ERR_NO_WEIGHTS
+    with pytest.raises(diee_amd.DieeError) as ei:
+        e.forward_t(roots)
+    assert ei.value.status == diee_amd.ERR_NO_WEIGHTS
+    with pytest.raises(diee_amd.DieeError) as ei:               # wrong blob size
+        e.load_weights(np.zeros(10, np.float32))
+    assert ei.value.status == diee_amd.ERR_ARG
+    e.load_weights(diee_amd.random_weights(0))
+    bad = roots.copy(); bad["roll"] = 0
+    with pytest.raises(diee_amd.DieeError) as ei:               # "die has not been rolled!" (backgammon_logic.rs:404)
+        e.alpha_mcts_parallel(bad, cfg)
+    assert ei.value.status == diee_amd.ERR_ARG
+    with pytest.raises(diee_amd.DieeError) as ei:               # iterations = 0 would divide 0/0 in the reference
+        e.self_play_parallel(2, diee_amd.MctsConfig.default(0))
+    assert ei.value.status == diee_amd.ERR_ARG
+    e.close()
+    # a tree arena that is too small is reported, never silently truncated
+    monkeypatch.setenv("DIEE_NODES_PER_EXPANSION", "1")
+    e2 = diee_amd.Engine(0); e2.load_weights(diee_amd.random_weights(0))
+    with pytest.raises(diee_amd.DieeError) as ei:
+        e2.alpha_mcts_parallel(roots, diee_amd.MctsConfig.default(64))
+    assert ei.value.status == diee_amd.ERR_CAPACITY
+    monkeypatch.delenv("DIEE_NODES_PER_EXPANSION")
+    r = e2.alpha_mcts_parallel(roots, diee_amd.MctsConfig.default(8))      # the engine stays usable afterwards
+    assert np.allclose(r["probs"].sum(1), 1.0, atol=1e-5)
+    e2.close()
+
+
+def test_8192_games_on_one_gpu(oracle):
+    """BASELINE configs[2] puts 8192 games on 8 GPUs; one MI355X's 288 GB holds all of them too"""
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    cfg = diee_amd.MctsConfig(iterations=3, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    out = e.self_play_parallel(8192, cfg, 1.25, 5, max_steps=2, fetch=False)
+    st = out["stats"]
+    assert st["move_steps"] == 2 and st["plies"] == 2 * 8192 and st["nn_evals"] == 2 * 4 * 8192
+    assert st["illegal_decodes"] == 0
+    e.close()
