@@ -81,7 +81,12 @@ def main():
         dist.init_process_group("nccl")            # "nccl" is RCCL on ROCm
 
     import diee_amd
-    eng = diee_amd.Engine(local_rank)              # raises without a GPU: there is no CPU path
+    dev = local_rank
+    if dist is not None:
+        import torch
+        if torch.cuda.device_count() <= local_rank:   # a launcher that narrows HIP_VISIBLE_DEVICES to one GPU per rank
+            dev = 0
+    eng = diee_amd.Engine(dev)                     # raises without a GPU: there is no CPU path
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     first_id = ddist.shard_first_game_id(rank, args.games)

@@ -226,16 +226,17 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
 // workgroup, partial tiles reduced through LDS) and a workgroup owns only GT boards x 32 channels:
 // 8x more workgroups than the large-batch geometry, 36 instead of 144 dependent k-steps per wave,
 // and each wave requests its whole 36 KiB weight stream up front.
-template <int MODE, int GT>
-__global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__ act,       // [M][256] bf16
+template <int MODE, int GT, int NSPLIT = 4>
+__global__ __launch_bounds__(64 * NSPLIT) void k_conv3x3_sk(const uint16_t* __restrict__ act,       // [M][256] bf16
                                                     const u32x4* __restrict__ wpack,       // [N/32][144][64] x 16 B
                                                     const float* __restrict__ bias,
                                                     const uint16_t* __restrict__ res,
                                                     uint16_t* __restrict__ out, float* __restrict__ out_v,
                                                     int M, int N) {
     constexpr int C_IN = 256, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = C_IN * 2 + 16, CPR = 32;
-    constexpr int KS = 36;                          // k-steps per wave: 4 channel steps x 9 taps
-    constexpr int PF = GT <= 2 ? 36 : 18;           // weight fragments in flight per wave
+    constexpr int NT = 64 * NSPLIT;
+    constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
+    constexpr int PF = GT <= 2 ? KS : 18;           // weight fragments in flight per wave
     constexpr int PRS = 32 * 4 + 16;                // partial-tile row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* part = smem;                              // [4 waves][MF*32 rows][32] f32, aliases the activation tile
@@ -249,13 +250,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < PF; ++i) bq[i] = wp[i * 64];
 
-    for (int i = tid; i < ROWS * CPR; i += 256) {
+    for (int i = tid; i < ROWS * CPR; i += NT) {
         const int r = i / CPR, ch = i % CPR;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row0 + r < M) v = *(const u32x4*)(act + (size_t)(row0 + r) * C_IN + ch * 8);
         *(u32x4*)(smem + r * RS + ch * 16) = v;
     }
-    for (int i = tid; i < CPR + 3; i += 256) *(u32x4*)(smem + ROWS * RS + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < CPR + 3; i += NT) *(u32x4*)(smem + ROWS * RS + i * 16) = u32x4{0u, 0u, 0u, 0u};
     int base[9][MF];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
             const int dy = t / 3 - 1, dx = t % 3 - 1;
             const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
             const int src = ok ? R + 6 * dy + dx : ROWS;
-            base[t][f] = src * RS + (lane >> 5) * 16 + wave * 4 * 32;     // this wave's channel quarter
+            base[t][f] = src * RS + (lane >> 5) * 16 + wave * (16 / NSPLIT) * 32;     // this wave's share of the channels
         }
     }
     __syncthreads();
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
             *(float*)(part + ((wave * MF * 32 + r) * PRS) + (lane & 31) * 4) = acc[f][i];
         }
     __syncthreads();
-    for (int i = tid; i < ROWS * 4; i += 256) {
+    for (int i = tid; i < ROWS * 4; i += NT) {
         const int r = i >> 2, c8 = i & 3;
         const int gr = row0 + r;
         if (gr >= M) continue;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_sk(const uint16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bias[nslice * 32 + c8 * 8 + j];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NSPLIT; ++w) {
             const float4 lo = *(const float4*)(part + (w * MF * 32 + r) * PRS + c8 * 32);
             const float4 hi = *(const float4*)(part + (w * MF * 32 + r) * PRS + c8 * 32 + 16);
             v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
@@ -709,18 +710,18 @@ static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, 
                        out_v, G * 24, N);
 }
 
-template <int MODE, int GT>
+template <int MODE, int GT, int NSPLIT = 4>
 static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
                            uint16_t* out, int G, int N, float* out_v = nullptr) {
     static bool attr_set = false;
     constexpr int rows = GT * 24, mf = (rows + 31) / 32;
-    constexpr int lds_a = (rows + 1) * 528 + 16 * 34 + 64, lds_p = 4 * mf * 32 * (32 * 4 + 16);
+    constexpr int lds_a = (rows + 1) * 528 + 16 * 34 + 64, lds_p = NSPLIT * mf * 32 * (32 * 4 + 16);
     constexpr int lds = lds_a > lds_p ? lds_a : lds_p;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv3x3_sk<MODE, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_conv3x3_sk<MODE, GT, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT>), dim3((G + GT - 1) / GT, N / 32), dim3(256), lds, st, act,
+    hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT, NSPLIT>), dim3((G + GT - 1) / GT, N / 32), dim3(64 * NSPLIT), lds, st, act,
                        (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
 }
 
@@ -781,8 +782,9 @@ static int pick_variant(int G) {
     // 4 boards x 128 channels per workgroup (up to 3 workgroups per CU); small batches are latency-bound
     // and want the split-K geometry (8x more workgroups, 4x shorter dependent chains)
     if (G > 320) return 2;          // 4 boards x 128 channels, 4 waves (only reached when the fused tower is disabled)
-    if (G > 80) return 6;           // split-K, 4 boards x 32 channels
-    return 5;                       // split-K, 2 boards x 32 channels
+    if (G > 80) return 6;           // split-K over 4 waves, 4 boards x 32 channels
+    if (G > 72) return 5;           // split-K over 4 waves, 2 boards x 32 channels
+    return 17;                      // split-K over 8 waves, 2 boards x 32 channels
 }
 
 template <int MODE>
@@ -795,6 +797,8 @@ static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wp
         case 4: conv_launch<256, MODE, 2, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
         case 5: conv_sk_launch<MODE, 2>(st, act, wpack, bias, res, out, G, N); break;
         case 6: conv_sk_launch<MODE, 4>(st, act, wpack, bias, res, out, G, N); break;
+        case 17: conv_sk_launch<MODE, 2, 8>(st, act, wpack, bias, res, out, G, N); break;   // split-K over 8 waves
+        case 18: conv_sk_launch<MODE, 4, 8>(st, act, wpack, bias, res, out, G, N); break;
         case 8: conv_launch<256, MODE, 4, 4, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
         case 9: conv_launch<256, MODE, 4, 4, 1, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;   // timing only: no weight reloads
         case 10: conv_launch<256, MODE, 4, 4, 1, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;  // timing only: no LDS reads
