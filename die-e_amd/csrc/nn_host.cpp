@@ -90,6 +90,19 @@ void pack_conv16(const std::vector<float>& w, int cout, int cin, std::vector<uin
                     }
 }
 
+// init block for the 16x16x32 path: one 32-channel k-step per tap, channels >= cin are zero
+void pack_init16(const std::vector<float>& w, int cout, int cin, std::vector<uint16_t>& out) {
+    const int nfr = cout / 16;
+    out.assign((size_t)nfr * 9 * 64 * 8, 0);
+    for (int s = 0; s < nfr; ++s)
+        for (int t = 0; t < 9; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = s * 16 + (lane & 15), c = 8 * (lane >> 4) + j;
+                    if (c < cin) out[(((size_t)s * 9 + t) * 64 + lane) * 8 + j] = f2bf_host(w[((size_t)n * cin + c) * 9 + t]);
+                }
+}
+
 }  // namespace
 
 size_t weights_count_bg() { return layout().total; }
@@ -130,6 +143,7 @@ void Engine::load_weights(const float* blob, size_t n) {
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
+    if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_TOWER_TABLE")) {      // development / tests
         net->tower_table.clear();
         std::string t(v);
@@ -168,6 +182,8 @@ void Engine::load_weights(const float* blob, size_t n) {
         sync();     // pk / bp are reused
     };
     up_conv(0, L.init_conv, L.init_bn, 256, 16);
+    pack_init16(w, 256, CIN, pk);                  // `w` still holds the folded init-block weights
+    W.winit16.ensure(pk.size()); h2d(W.winit16.p, pk.data(), pk.size()); sync();
     for (int i = 0; i < BLOCKS; ++i) { up_conv(1 + 2 * i, L.c1[i], L.b1[i], 256, 256); up_conv(2 + 2 * i, L.c2[i], L.b2[i], 256, 256); }
     {   // heads share one conv launch: channels 0..31 policy (nnet.rs:76), 32..34 value (nnet.rs:88)
         std::vector<float> wp, bp, wv, bv;
@@ -177,6 +193,14 @@ void Engine::load_weights(const float* blob, size_t n) {
         memcpy(b.data(), bp.data(), sizeof(float) * 32); memcpy(b.data() + 32, bv.data(), sizeof(float) * 3);
         pack_conv(w, 35, F, 64, 256, pk);
         W.wconv[39].ensure(pk.size()); h2d(W.wconv[39].p, pk.data(), pk.size());
+        sync();
+        {   // the same head convs as 16-column fragments (4 fragments = 64 channels, 35 real)
+            std::vector<float> w64((size_t)64 * F * 9, 0.f);
+            memcpy(w64.data(), w.data(), sizeof(float) * w.size());
+            pack_conv16(w64, 64, F, pk);
+            W.whead16.ensure(pk.size()); h2d(W.whead16.p, pk.data(), pk.size());
+            sync();
+        }
         std::vector<float> bpad(64, 0.f); memcpy(bpad.data(), b.data(), sizeof(float) * 35);
         W.bconv[39].ensure(64); h2d(W.bconv[39].p, bpad.data(), (size_t)64);
         sync();
@@ -222,14 +246,19 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     nn_reserve(e, G);
     hipStream_t st = e.stream;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
+    const int tgeom = W.tower_geometry_for(G);
+    const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch
     // the init block reads the states and builds the input planes itself (no separate planes kernel)
-    launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+    if (!whole)
+        launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
     // sampled timing of the 38-launch tower chain: one HIP-event pair per sampled forward (per-launch
     // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
-    const int tgeom = W.tower_geometry_for(G);
-    if (tgeom >= 0) {
+    if (whole) {
+        launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
+                     W.hp.p, W.hv.p, G);
+    } else if (tgeom >= 0) {
         launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
     } else {
         for (int i = 0; i < BLOCKS; ++i) {
@@ -243,7 +272,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         const bool fused = tgeom >= 0;
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, fused ? 1 : 38, fused});
     }
-    launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
+    if (!whole) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
     launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
