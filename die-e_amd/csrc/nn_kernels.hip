@@ -53,7 +53,7 @@ __global__ void k_planes_bf16(const BgState* __restrict__ states, uint32_t n, ui
 // MODE 2: heads: channels 0..31 -> policy features bf16 [g][p*32+c], 32..34 -> value features f32
 //         [g][p*3+c], both after ReLU       (nnet.rs:75-79, 87-91)
 // GT = boards per workgroup (rows = 24*GT, padded to MF fragments of 32), NW = waves (32 channels each).
-template <int C_IN, int MODE, int GT, int NW, int PD = 1, int DBG = 0, int NF = 1>
+template <int C_IN, int MODE, int GT, int NW>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict__ act,      // [M][C_IN] bf16
                                                      const u32x4* __restrict__ wpack,      // [N/32][KSTEPS][64] x 16 B
                                                      const float* __restrict__ bias,       // [N]
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     constexpr int CSTEPS = C_IN / 16;              // channel steps of 16
     constexpr int KSTEPS = CSTEPS * 9;
     constexpr int UNR = CSTEPS >= 2 ? 2 : 1;       // channel steps per loop body (18 / 9 MFMA k-steps)
+    constexpr int NF = 1, PD = 1;                  // one 32-channel N-fragment per wave; LDS reads one k-step ahead
     constexpr int NC = NW * NF * 32;               // output channels per workgroup
     constexpr int ORS = NC * 4 + 16;               // epilogue tile row stride (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
             for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.0f;
 
     // software pipeline: A fragments of k-step s+PD are read from LDS while the MFMAs of k-step s
-    // issue (PD = 2 when a k-step has few MFMAs: LDS latency > 3 MFMAs); the weight fragment of
-    // k-step s+9 is requested from L2 at k-step s.
+    // issue (a distance of 2 k-steps measured no faster); the weight fragment of k-step s+9 is requested
+    // from L2 at k-step s.
     constexpr int NB = PD + 1;                     // A-fragment ring
     static_assert(CSTEPS / UNR == 1 || (9 * UNR) % NB == 0, "ring index must be static");
     bf16x8 a[NB][MF];
@@ -141,20 +142,19 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
     for (int d = 0; d < PD; ++d)
 #pragma unroll
         for (int f = 0; f < MF; ++f) a[d][f] = *(const bf16x8*)(smem + base[d % 9][f] + (d / 9) * 32);
-    for (int it = 0; it < (DBG == 3 ? 0 : CSTEPS / UNR); ++it) {
+    for (int it = 0; it < CSTEPS / UNR; ++it) {
 #pragma unroll
         for (int u = 0; u < 9 * UNR; ++u) {
             const int t = u % 9, cur = u % NB, nxt = (u + PD) % NB;
             const int un = u + PD;                                 // k-step to prefetch (inside / after this body)
             const int tn = un % 9;
             const int csn = it * UNR + un / 9;                     // may run past CSTEPS at the very end: reads padding, unused
-            if (DBG != 2)
 #pragma unroll
             for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[tn][f] + csn * 32);
             bf16x8 b[NF];
 #pragma unroll
             for (int q = 0; q < NF; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[t][q]);
-            if (DBG != 1) {
+            {
                 const int cs_pf = it * UNR + u / 9 + 1;            // same tap, next channel step
 #pragma unroll
                 for (int q = 0; q < NF; ++q)
@@ -858,17 +858,17 @@ static constexpr int conv_lds_bytes() {
     return a > o ? a : o;
 }
 
-template <int C_IN, int MODE, int GT, int NW, int PD = 1, int DBG = 0, int NF = 1>
+template <int C_IN, int MODE, int GT, int NW>
 static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
                         uint16_t* out, float* out_v, int G, int N) {
     static bool attr_set = false;
-    constexpr int lds = conv_lds_bytes<C_IN, GT, NW * NF * 32>();
+    constexpr int lds = conv_lds_bytes<C_IN, GT, NW * 32>();
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW, PD, DBG, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const dim3 grid((G + GT - 1) / GT, N / (32 * NW * NF)), block(64 * NW);
-    hipLaunchKernelGGL((k_conv3x3<C_IN, MODE, GT, NW, PD, DBG, NF>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out,
+    const dim3 grid((G + GT - 1) / GT, N / (32 * NW)), block(64 * NW);
+    hipLaunchKernelGGL((k_conv3x3<C_IN, MODE, GT, NW>), grid, block, lds, st, act, (const u32x4*)wpack, bias, res, out,
                        out_v, G * 24, N);
 }
 
@@ -956,7 +956,7 @@ void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t
     hipLaunchKernelGGL(k_planes_bf16, dim3((n * 24 + 255) / 256), dim3(256), 0, st, (const BgState*)states, n, out);
 }
 
-static int g_conv_variant = -1;     // development override (diee_dev_conv_bench): <= 0 auto, 1..7 fixed
+static int g_conv_variant = -1;     // development override (diee_dev_conv_bench): <= 0 auto, else a fixed geometry id
 void nn_set_conv_variant(int v) { g_conv_variant = v; }
 
 // geometry by batch size: keep ~>=256 workgroups in flight while boards per workgroup (weight reuse) stay high
@@ -983,15 +983,6 @@ static void conv256_dispatch(hipStream_t st, const uint16_t* act, const void* wp
         case 6: conv_sk_launch<MODE, 4>(st, act, wpack, bias, res, out, G, N); break;
         case 17: conv_sk_launch<MODE, 2, 8>(st, act, wpack, bias, res, out, G, N); break;   // split-K over 8 waves
         case 18: conv_sk_launch<MODE, 4, 8>(st, act, wpack, bias, res, out, G, N); break;
-        case 8: conv_launch<256, MODE, 4, 4, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
-        case 9: conv_launch<256, MODE, 4, 4, 1, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;   // timing only: no weight reloads
-        case 10: conv_launch<256, MODE, 4, 4, 1, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;  // timing only: no LDS reads
-        case 13: conv_launch<256, MODE, 4, 4, 1, 0, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;   // 4 boards x 256 ch, 2 N-frags per wave
-        case 14: conv_launch<256, MODE, 4, 2, 1, 0, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;   // 4 boards x 128 ch, 2 waves x 2 N-frags
-        case 15: conv_launch<256, MODE, 4, 4, 1, 3>(st, act, wpack, bias, res, out, out_v, G, N); break;      // timing only: no main loop
-        case 16: conv_launch<256, MODE, 4, 4, 1, 3, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
-        case 11: conv_launch<256, MODE, 8, 4, 1, 1>(st, act, wpack, bias, res, out, out_v, G, N); break;
-        case 12: conv_launch<256, MODE, 8, 4, 1, 2>(st, act, wpack, bias, res, out, out_v, G, N); break;
         default: conv_sk_launch<MODE, 8>(st, act, wpack, bias, res, out, G, N); break;
     }
 }

@@ -171,7 +171,8 @@ diee_status diee_probe_dice(diee_ctx*, uint64_t seed, const uint32_t* ctr /*[n][
 
 /* development probe: average device time (us, HIP events) of the 3x3 tower conv kernel without /
  * with the residual epilogue at batch G, and of a whole forward pass; variant 0 = geometry picked
- * by batch size, 1..4 = fixed (8x128ch/4 waves, 4x128/4, 2x64/2, 2x32/1 boards x channels/waves) */
+ * by batch size; 1..4 per-layer (8x128ch/4 waves, 4x128/4, 2x64/2, 2x32/1 boards x channels/waves);
+ * 5/6/7 and 17/18 split-K over 4 / 8 waves; 100..105 whole tower in one launch (fused geometries) */
 diee_status diee_dev_conv_bench(diee_ctx*, int G, int variant, int reps, float* us_mode0,
                                 float* us_mode1, float* us_forward);
 
