@@ -9,7 +9,8 @@ OUT = os.path.join(HERE, "libdiee.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("DIEE_EXTRA_FLAGS", "").split()      # development (e.g. -DDIEE_TOWER_ABLATE=1)
+COMMON = EXTRA + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           f"--offload-arch={ARCH}"]
 
 

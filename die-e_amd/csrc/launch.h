@@ -27,6 +27,7 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
                   uint16_t* x_out, int G);
 void launch_net16(hipStream_t st, int geometry, const void* states, const void* winit, const float* binit, const void* wt,
                   const float* bt, const void* whead, const float* bhead, uint16_t* hp, float* hv, int G);
+void nn_set_tower_dbg(unsigned long long* p);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);

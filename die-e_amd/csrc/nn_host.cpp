@@ -1,6 +1,8 @@
 // nn_host.cpp -- ResNet weights (blob layout of include/diee.h, BatchNorm folding, MFMA fragment
 // packing) and the forward pass driver.  Reference: src/alphazero/nnet.rs:57-133.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -247,7 +249,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     hipStream_t st = e.stream;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
     const int tgeom = W.tower_geometry_for(G);
-    const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch
+    const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch (development)
     // the init block reads the states and builds the input planes itself (no separate planes kernel)
     if (!whole)
         launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
@@ -333,7 +335,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
-    if (variant >= 100 && variant <= 105) W.tower_table = {{0, variant - 100}};
+    if (variant >= 100 && variant <= 109) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
@@ -344,6 +346,20 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     HIPCHK(hipEventSynchronize(b));
     HIPCHK(hipEventElapsedTime(&ms, a, b));
     *us_forward = ms * 1e3f / reps;
+    if (getenv("DIEE_TOWER_CLOCK")) {      // diagnostic build (-DDIEE_TOWER_ABLATE=3): median in-kernel clock of the fused tower
+        DevBuf<unsigned long long> dbg; dbg.ensure(4096);
+        HIPCHK(hipMemsetAsync(dbg.p, 0, 4096 * 8, st));
+        nn_set_tower_dbg(dbg.p);
+        const auto saved2 = W.tower_table; W.tower_table = {{0, variant >= 100 ? variant - 100 : 5}};
+        for (int r = 0; r < 200; ++r) nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
+        W.tower_table = saved2; nn_set_tower_dbg(nullptr);
+        std::vector<unsigned long long> h(4096);
+        e.d2h(h.data(), dbg.p, (size_t)4096); e.sync();
+        std::vector<double> mhz;
+        for (int i = 0; i < 2048; ++i) if (h[2 * i + 1]) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+        std::sort(mhz.begin(), mhz.end());
+        if (!mhz.empty()) fprintf(stderr, "[diee] fused tower in-kernel clock: median %.0f MHz (min %.0f, max %.0f) over %zu workgroups; %llu shader cycles\n", mhz[mhz.size() / 2], mhz.front(), mhz.back(), mhz.size(), h[0]);
+    }
     nn_set_conv_variant(0);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
 }

@@ -19,10 +19,11 @@ struct NetWeights {
     uint16_t* wl(int layer) { return (layer >= 1 && layer <= 38) ? wtower.p + (size_t)(layer - 1) * 8 * 144 * 64 * 8 : wconv[layer].p; }
     float* bl(int layer) { return (layer >= 1 && layer <= 38) ? btower.p + (size_t)(layer - 1) * 256 : bconv[layer].p; }
     // fused-tower dispatch: the first entry with G > min_games wins; batches below every entry run per-layer kernels.
-    // Measured on MI355X (scripts/fwd_sweep*.py): 16x16x32 MFMA with 4 boards per workgroup above 768 boards,
-    // 3 boards above 512, 2 boards above 200.  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
+    // Measured on MI355X (scripts/fwd_sweep*.py, scripts/tower_clock.py): 16x16x32 MFMA, 8 waves per workgroup (two per
+    // SIMD: one wave's loads overlap the other's MFMAs: 79-81 % MFMA issue efficiency vs 62-67 % with one wave per SIMD),
+    // 4 boards per workgroup above 768 boards, 3 boards above 512, 2 boards above 200.  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
-    std::vector<TowerRule> tower_table = {{768, 5}, {512, 4}, {200, 3}};
+    std::vector<TowerRule> tower_table = {{768, 8}, {512, 7}, {200, 3}};
     int tower_geometry_for(int G) const {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
         return -1;

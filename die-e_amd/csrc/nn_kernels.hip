@@ -16,6 +16,10 @@
 #include "bg_device.h"
 #include "launch.h"
 
+#ifndef DIEE_TOWER_ABLATE
+#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps
+#endif
+
 namespace diee {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -493,7 +497,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
     auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
 #pragma unroll
     for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < (DIEE_TOWER_ABLATE == 1 ? 0 : 4); ++it) {
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
@@ -522,7 +526,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
     // layout (col = lane&15, row = (lane>>4)*4 + i) a lane holds FOUR CONSECUTIVE CHANNELS of one board position:
     // one 8-byte LDS write (and residual read) per tile instead of four 2-byte ones.
 #pragma unroll
-    for (int q = 0; q < NFR; ++q) {
+    for (int q = 0; q < (DIEE_TOWER_ABLATE == 2 ? 0 : NFR); ++q) {
         const int n0 = (wave * NFR + q) * 16 + (lane >> 4) * 4;
         const float4 bv = *(const float4*)(bias + n0);
 #pragma unroll
@@ -548,7 +552,8 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 
 template <int GT, int NW, int PF>
 __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict__ x_in, const u32x4* __restrict__ wt,
-                                                    const float* __restrict__ bias, uint16_t* __restrict__ x_out, int M) {
+                                                    const float* __restrict__ bias, uint16_t* __restrict__ x_out, int M,
+                                                    unsigned long long* dbg /* clock stamps, diagnostic builds only */) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, RS = 528, NT = 64 * NW, NFR = 16 / NW;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -592,6 +597,8 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         }
     }
     __syncthreads();
+    unsigned long long t0 = 0, r0 = 0;
+    if (DIEE_TOWER_ABLATE == 3) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (int blk = 0; blk < 19; ++blk) {
         const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTower16LayerStride;
@@ -599,6 +606,10 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         const u32x4* w3 = blk < 18 ? w2 + kTower16LayerStride : w2;
         tower_layer16<false, GT, NW, PF>(tx, th, w1, w2, bias + (2 * blk) * 256, basep, bq, lane, wave);
         tower_layer16<true, GT, NW, PF>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, basep, bq, lane, wave);
+    }
+    if (DIEE_TOWER_ABLATE == 3 && dbg && tid == 0) {      // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+        dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     for (int i = tid; i < ROWS * 32; i += NT) {
         const int r = i >> 5, ch = i & 31;
@@ -901,6 +912,9 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
     hipLaunchKernelGGL((k_tower<GT, NF, PF>), dim3((G + GT - 1) / GT), dim3(64 * (8 / NF)), lds, st, x_in,
                        (const u32x4*)wt, bias, x_out, G * 24);
 }
+static unsigned long long* g_tower_dbg = nullptr;     // diagnostic builds: per-workgroup clock stamps
+void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
+
 template <int GT, int NW, int PF>
 static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
     static bool attr_set = false;
@@ -911,7 +925,7 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
         attr_set = true;
     }
     hipLaunchKernelGGL((k_tower16<GT, NW, PF>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
-                       (const u32x4*)wt, bias, x_out, G * 24);
+                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg);
 }
 template <int GT, int NW, int PF>
 static void net16_launch(hipStream_t st, const Net16Params& P) {
@@ -935,8 +949,8 @@ void launch_net16(hipStream_t st, int geometry, const void* states, const void* 
     }
 }
 
-// geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2/3/4: 16x16x32 MFMA (wt16 = 16-column fragments) with
-// 4 / 2 / 3 boards per workgroup
+// geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9: 16x16x32 MFMA (wt16 = 16-column fragments):
+// 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 3, 7, 8)
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
                   uint16_t* x_out, int G) {
     switch (geometry) {
@@ -945,6 +959,10 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
         case 2: tower16_launch<4, 4, 6>(st, x_in, wt16, bias, x_out, G); break;
         case 5: tower16_launch<4, 4, 3>(st, x_in, wt16, bias, x_out, G); break;
         case 3: tower16_launch<2, 8, 9>(st, x_in, wt16, bias, x_out, G); break;
+        case 6: tower16_launch<4, 8, 6>(st, x_in, wt16, bias, x_out, G); break;     // 4 boards, 8 waves (2 per SIMD)
+        case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G); break;
+        case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G); break;
+        case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G); break;
         default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G); break;
     }
 }

@@ -115,9 +115,9 @@ def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("geom", [3, 4, 5])
+@pytest.mark.parametrize("geom", [3, 4, 5, 7, 8])
 def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
-    """the fused tower on v_mfma_f32_16x16x32_bf16 (2 / 3 / 4 boards per workgroup): same network, different
+    """the fused tower on v_mfma_f32_16x16x32_bf16 (2 / 3 / 4 boards per workgroup, 4 or 8 waves): same network, different
     MFMA shape, so equal to the 32x32x16 kernels up to fp32 summation order, and within the stated tolerance of fp32"""
     import diee_amd
     from oracle.nn_ref import parse, forward_t
