@@ -33,6 +33,7 @@ void Engine::check_overflow() {
     if (f) {
         HIPCHK(hipMemsetAsync(flags_dev.p, 0, sizeof(uint32_t), stream));
         sync();
+        if (f & 4u) throw EngineError(DIEE_ERR_HIP, "cluster tower: a workgroup handshake timed out (grid not co-resident?); set DIEE_TOWER_CL=none");
         throw EngineError(DIEE_ERR_CAPACITY, "device capacity overflow (sequence table / tree arena), flag=" + std::to_string(f));
     }
 }

@@ -28,6 +28,11 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
 void launch_net16(hipStream_t st, int geometry, const void* states, const void* winit, const float* binit, const void* wt,
                   const float* bt, const void* whead, const float* bhead, uint16_t* hp, float* hv, int G);
 void nn_set_tower_dbg(unsigned long long* p);
+// cluster tower: 38 layers in one launch for small batches; `sync` = kClusterMaxGroups counters 128 B apart (zeroed),
+// `err` gets bit 2 set if a cluster wait timed out.  false = not launched (grid would not be co-resident).
+constexpr int kClusterMaxGroups = 64;
+bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
+                          int G, uint32_t* sync, uint32_t* err);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);

@@ -146,6 +146,18 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;   // 0: keep init block / heads as separate launches
+    if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
+        net->cluster_table.clear();
+        std::string t(v);
+        size_t pos = 0;
+        while (pos < t.size() && t != "none") {
+            const size_t c = t.find(':', pos), e2 = t.find(',', pos);
+            if (c == std::string::npos) break;
+            net->cluster_table.push_back({atoi(t.substr(pos, c - pos).c_str()), atoi(t.substr(c + 1, (e2 == std::string::npos ? t.size() : e2) - c - 1).c_str())});
+            if (e2 == std::string::npos) break;
+            pos = e2 + 1;
+        }
+    }
     if (const char* v = getenv("DIEE_TOWER_TABLE")) {      // development / tests
         net->tower_table.clear();
         std::string t(v);
@@ -241,6 +253,20 @@ void nn_reserve(Engine& e, int G) {
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh)
+// small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
+// would not be co-resident on this device: the caller runs the per-layer kernels.
+static bool cluster_tower(Engine& e, NetWeights& W, int G) {
+    for (const auto& r : W.cluster_table) {
+        if (G > r.max_games) continue;
+        if (!W.cl_sync.p) {
+            W.cl_sync.ensure((size_t)kClusterMaxGroups * 32);
+            HIPCHK(hipMemsetAsync(W.cl_sync.p, 0, (size_t)kClusterMaxGroups * 32 * sizeof(uint32_t), e.stream));
+        }
+        return launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p);
+    }
+    return false;
+}
+
 void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev) {
     if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
     if (G <= 0) return;
@@ -256,13 +282,17 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     // sampled timing of the 38-launch tower chain: one HIP-event pair per sampled forward (per-launch
     // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int kind = 1;
     if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
     if (whole) {
         launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
                      W.hp.p, W.hv.p, G);
     } else if (tgeom >= 0) {
         launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
+    } else if (cluster_tower(e, W, G)) {
+        kind = 2;                                                   // all 38 layers, 8-workgroup clusters per board group
     } else {
+        kind = 0;
         for (int i = 0; i < BLOCKS; ++i) {
             launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
             // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
@@ -271,8 +301,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     }
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        const bool fused = tgeom >= 0;
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, fused ? 1 : 38, fused});
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind});
     }
     if (!whole) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
@@ -287,7 +316,8 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     for (auto& p : W.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            if (p.fused) { W.tower_seconds += ms * 1e-3; W.tower_launches += p.launches; W.tower_flops += p.flops; }
+            if (p.kind == 1) { W.tower_seconds += ms * 1e-3; W.tower_launches += p.launches; W.tower_flops += p.flops; }
+            else if (p.kind == 2) { W.cluster_seconds += ms * 1e-3; W.cluster_launches += p.launches; W.cluster_flops += p.flops; }
             else { W.conv_seconds += ms * 1e-3; W.conv_launches += p.launches; W.conv_flops += p.flops; }
         }
         W.free_events.push_back(p.a); W.free_events.push_back(p.b);
@@ -296,12 +326,14 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     if (stats) {
         stats->conv_seconds = W.conv_seconds; stats->conv_launches = W.conv_launches; stats->conv_flops = W.conv_flops;
         stats->tower_seconds = W.tower_seconds; stats->tower_launches = W.tower_launches; stats->tower_flops = W.tower_flops;
+        stats->cluster_seconds = W.cluster_seconds; stats->cluster_launches = W.cluster_launches; stats->cluster_flops = W.cluster_flops;
     }
 }
 void nn_reset_timing(Engine& e) {
     if (!e.net) return;
     e.net->conv_seconds = 0; e.net->conv_launches = 0; e.net->conv_flops = 0; e.net->forward_count = 0;
     e.net->tower_seconds = 0; e.net->tower_launches = 0; e.net->tower_flops = 0;
+    e.net->cluster_seconds = 0; e.net->cluster_launches = 0; e.net->cluster_flops = 0;
 }
 
 // development probe: average device time of the tower conv kernel (modes 0 and 1) at batch G
@@ -335,13 +367,16 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     HIPCHK(hipMemsetAsync(e.tmp_a.p, 1, (size_t)G * 32, st));
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
+    const auto saved_cl = W.cluster_table;
     if (variant >= 100 && variant <= 109) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
+    if (variant == 202 || variant == 204) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
+    else if (variant != 0) W.cluster_table.clear();
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
         nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
     }
-    W.sample_every = se; W.tower_table = saved_table;
+    W.sample_every = se; W.tower_table = saved_table; W.cluster_table = saved_cl;
     HIPCHK(hipEventRecord(b, st));
     HIPCHK(hipEventSynchronize(b));
     HIPCHK(hipEventElapsedTime(&ms, a, b));
@@ -378,6 +413,7 @@ void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* pol
     d2h((uint8_t*)policy, tmp_b.p, (size_t)n * 1352 * 4);
     d2h((uint8_t*)value, tmp_c.p, (size_t)n * 4);
     sync();
+    check_overflow();
 }
 
 }  // namespace diee

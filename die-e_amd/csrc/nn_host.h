@@ -28,6 +28,12 @@ struct NetWeights {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
         return -1;
     }
+    // cluster tower (k_tower_cl): batches of at most max_games boards run the 38 layers in one launch, boards_per_group
+    // boards per 8-workgroup cluster; tried in order, a batch no rule takes (or whose grid would not be co-resident)
+    // runs per-layer kernels.  DIEE_TOWER_CL="max:boards,max:boards" overrides ("none" disables).
+    struct ClusterRule { int max_games, boards_per_group; };
+    std::vector<ClusterRule> cluster_table = {{64, 2}, {128, 4}};
+    DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias
     bool loaded = false;
@@ -36,13 +42,13 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; bool fused; };
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; };   // kind 0 per-layer, 1 fused tower, 2 cluster tower
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     int sample_every = 17;
     uint64_t forward_count = 0;
-    double conv_seconds = 0, conv_flops = 0, tower_seconds = 0, tower_flops = 0;
-    uint64_t conv_launches = 0, tower_launches = 0;
+    double conv_seconds = 0, conv_flops = 0, tower_seconds = 0, tower_flops = 0, cluster_seconds = 0, cluster_flops = 0;
+    uint64_t conv_launches = 0, tower_launches = 0, cluster_launches = 0;
     hipEvent_t get_event() {
         if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
         hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;

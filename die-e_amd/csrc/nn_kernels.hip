@@ -16,6 +16,9 @@
 #include "bg_device.h"
 #include "launch.h"
 
+#ifndef DIEE_TOWER_SCHED
+#define DIEE_TOWER_SCHED 1        // 1 = sched_group_barrier interleave of each k-step's loads between its MFMAs (0: loads issued as a block)
+#endif
 #ifndef DIEE_TOWER_ABLATE
 #define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps
 #endif
@@ -346,13 +349,215 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_conv3x3_sk(const uint16_t* __re
     }
 }
 
+// Small-batch tower in ONE launch ("cluster tower").  k_conv3x3_sk's geometry -- GT boards x 32 channels per
+// workgroup, K split over 8 waves -- is kept for all 38 layers; the 8 workgroups that own the 8 channel slices of
+// one board group form a cluster: a layer's output goes to global memory (the X / H ping-pong of the per-layer path)
+// and the cluster meets on one counter per board group before the next layer's tile is staged.  What a launch
+// boundary costs the per-layer path (~2 us of gap, cold weight loads, tile staging behind them) shrinks to one
+// release / acquire pair: the next layer's 18 weight fragments are requested before the wait and arrive during it,
+// and the residual slice never leaves registers.  Arithmetic per output element is exactly k_conv3x3_sk<., GT, 8>'s
+// (same MFMA, same split, same reduction order): results are bit-identical to the per-layer path.
+//
+// Placement: workgroups are dispatched round-robin over the 8 XCDs, so the cluster of group g is given the linear
+// ids {g%8 + 8*(8*(g/8) + slice)}: all 8 on one XCD, sharing its L2.  Correctness does not depend on that (the
+// handshake is an agent-scope release / acquire), only the latency does.  Every workgroup of the grid must be
+// resident at once (the launcher checks the occupancy); a wait is bounded and reports through `err` instead of hanging.
+constexpr int kTowerLayerStride = 8 * 144 * 64;          // u32x4 per layer (1.18 MB)
+constexpr int kClusterSpinLimit = 1 << 18;
+
+// device-coherent 16-byte accesses for data other workgroups exchange inside a launch: relaxed agent-scope atomics
+// (global_load/store_dwordx2 sc1) reach the coherent level themselves, so the handshake needs no L2-wide
+// write-back / invalidate (an agent-scope fence costs ~0.1 us per wave and serialises per XCD: measured 19 us per layer)
+__device__ __forceinline__ u32x4 ld_coherent16(const uint16_t* p) {
+    const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+}
+__device__ __forceinline__ void st_coherent16(uint16_t* p, u32x4 v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Ready flag carried by the data: activations are post-ReLU bf16, so their sign bits are free.  The output of layer w
+// is written with the sign bit of the first element of every 8-byte word set to tag_of(w); consecutive writes into the
+// same buffer (w, w+2) carry opposite tags, so a consumer that polls its tile with 8-byte coherent loads knows word by
+// word when the new layer has landed: no store acknowledgement, counter update or counter poll on the critical path.
+// (w = 0 writes plain data over unknown leftovers, so that one hand-over uses the counter; w = 37 is the tower output.)
+__device__ __forceinline__ uint32_t tag_of(int w) { return (uint32_t)(((w >> 1) ^ w) & 1) << 15; }
+
+template <int GT>
+__global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                       // [M][256] bf16: init block output in, tower output out
+                                                  uint16_t* H,                       // [M][256] bf16 scratch (conv1 outputs)
+                                                  const u32x4* __restrict__ wt,      // [38][8][144][64] x 16 B
+                                                  const float* __restrict__ bias,    // [38][256]
+                                                  int M, int n_groups,
+                                                  uint32_t* sync,                    // [n_groups] counters, 128 B apart, zero between launches
+                                                  uint32_t* err) {
+    constexpr int NSPLIT = 8, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 512, KS = 18;
+    constexpr int PRS = 32 * 4 + 16;
+    static_assert(ROWS * 4 <= NT, "one output chunk per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* part = smem;                              // [8 waves][MF*32 rows][32] f32, aliases the activation tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int nslice = j & 7, grp = xcd + 8 * (j >> 3);
+    if (grp >= n_groups) return;
+    const int row0 = grp * ROWS;
+    uint32_t* cnt = sync + grp * 32;
+
+    const u32x4* wp = wt + ((size_t)nslice * 144 + wave * KS) * 64 + lane;
+    u32x4 bq[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) bq[i] = wp[i * 64];
+
+    int base[9][MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int R = 32 * f + (lane & 31);
+        const int p = R % 24, y = p / 6, x = p % 6;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+            const int src = ok ? R + 6 * dy + dx : ROWS;
+            base[t][f] = src * RS + (lane >> 5) * 16 + wave * 2 * 32;     // this wave's 2 channel steps
+        }
+    }
+    // this thread's output chunk (row r, 8 channels) and its residual: the block input, kept in registers
+    const int er = tid >> 2, ec8 = tid & 3, egr = row0 + er;
+    const bool ework = tid < ROWS * 4 && egr < M;
+    const size_t eoff = (size_t)egr * 256 + nslice * 32 + ec8 * 8;
+    u32x4 resreg = {0u, 0u, 0u, 0u};
+    if (ework) resreg = *(const u32x4*)(X + eoff);
+    // a wait timed out, now or in an earlier launch (reported through err): stop waiting, finish the launch
+    bool dead = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;
+
+    for (int l = 0; l < 38; ++l) {
+        const uint16_t* in = (l & 1) ? H : X;
+        uint16_t* out = (l & 1) ? X : H;
+        const float4 bias_lo = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8);      // requested ahead of the epilogue
+        const float4 bias_hi = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8 + 4);
+        if (l == 1) {
+            // ---- first hand-over (H holds unknown leftovers): meet on the group's counter ----
+            if (tid == 0 && !dead) {
+                int spins = 0;
+                while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u) < 0) {
+                    if (++spins > kClusterSpinLimit) { atomicOr(err, 4u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();                        // the tile loads below are device-coherent themselves
+        }
+        // ---- stage the activation tile; from layer 2 on the data is its own ready flag (see tag_of) ----
+        {
+            constexpr int NCH = ROWS * CPR / NT;    // 16-byte chunks per thread: all requested before the first is stored
+            static_assert(ROWS * CPR % NT == 0, "whole chunks per thread");
+            u32x4 v[NCH];
+            const uint32_t want = l >= 2 ? tag_of(l - 1) : 0u;
+            for (int spins = 0;; ++spins) {
+                // all chunks are requested back to back (rows past the batch re-read its last row: no branch, no wait in between)
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int gr = row0 + (tid + k * NT) / CPR;
+                    v[k] = ld_coherent16(in + (size_t)(gr < M ? gr : M - 1) * 256 + (tid % CPR) * 8);
+                }
+                uint32_t bad = 0u;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
+                if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
+                if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
+            }
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (row0 + (tid + k * NT) / CPR >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                v[k][0] &= ~0x8000u; v[k][2] &= ~0x8000u;
+                *(u32x4*)(smem + ((tid + k * NT) / CPR) * RS + (tid % CPR) * 16) = v[k];
+            }
+        }
+        if (tid < CPR + 3) *(u32x4*)(smem + ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};      // zero row
+        __syncthreads();
+
+        f32x16 acc[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+        bf16x8 a[2][MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
+        const u32x4* wn = wp + (size_t)(l < 37 ? l + 1 : l) * kTowerLayerStride;     // next layer's fragments (last layer: reloads its own, unused)
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
+#pragma unroll
+            for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u]);
+            bq[u] = wn[u * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        __syncthreads();                            // every wave is done reading the activation tile
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                *(float*)(part + ((wave * MF * 32 + r) * PRS) + (lane & 31) * 4) = acc[f][i];
+            }
+        __syncthreads();
+        if (ework) {
+            float v[8] = {bias_lo.x, bias_lo.y, bias_lo.z, bias_lo.w, bias_hi.x, bias_hi.y, bias_hi.z, bias_hi.w};
+#pragma unroll
+            for (int w = 0; w < NSPLIT; ++w) {
+                const float4 lo = *(const float4*)(part + (w * MF * 32 + er) * PRS + ec8 * 32);
+                const float4 hi = *(const float4*)(part + (w * MF * 32 + er) * PRS + ec8 * 32 + 16);
+                v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+            }
+            if (l & 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] += __uint_as_float(resreg[k] << 16);
+                    v[2 * k + 1] += __uint_as_float(resreg[k] & 0xffff0000u);
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x0 = v[2 * k] > 0.0f ? v[2 * k] : 0.0f, x1 = v[2 * k + 1] > 0.0f ? v[2 * k + 1] : 0.0f;
+                o[k] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
+            }
+            if (l & 1) resreg = o;                  // block output = next block's input
+            const uint32_t tg = l < 37 ? tag_of(l) : 0u;             // the tower output itself leaves untagged
+            o[0] |= tg; o[2] |= tg;
+            st_coherent16(out + eoff, o);
+        }
+        if (l == 0 || l == 37) {
+            // first hand-over: signal through the counter once this workgroup's stores are acknowledged;
+            // the second arrival round (end of launch) re-arms the counter for the next launch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t old = atomicAdd(cnt, 1u);
+                if (old == 15u) atomicExch(cnt, 0u);
+            }
+        } else {
+            __syncthreads();                        // partial tiles are consumed before the next tile is staged
+        }
+    }
+}
+
 // Large-batch variant: the whole 38-layer tower in ONE launch.  A workgroup owns 4 boards and all 256
 // channels (4 waves x 2 N-fragments x 3 M-fragments), so a layer's output tile is exactly the next
 // layer's input tile: activations ping-pong between two LDS tiles and never leave the CU, the
 // residual is read from LDS, and the per-layer launch gap, tile staging and global epilogue (6.4 us
 // of a 27 us layer) disappear.  Weights stream L2 -> registers as in k_conv3x3, the ring of 9 x 2
 // fragments runs ahead across layer boundaries.  One __syncthreads() per layer.
-constexpr int kTowerLayerStride = 8 * 144 * 64;          // u32x4 per layer (1.18 MB)
 
 // One tower layer inside the fused kernel.  GT boards per workgroup (MF M-fragments), NF N-fragments
 // per wave, PF = weight fragments in flight per wave and N-fragment (k-steps ahead; 9 or 18).
@@ -513,13 +718,26 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #pragma unroll
                 for (int q = 0; q < NFR; ++q) bq[u % PF][q] = src[(size_t)q * 72 * 64];
             }
+#if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int q = 0; q < NFR; ++q)
                     acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);   // D = W^T x act^T
+#if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
+#else
+            // interleave this k-step's loads between its MFMAs instead of issuing them as a block in front
+#pragma unroll
+            for (int i = 0; i < MF * NFR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+                if (i < MF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // 1 LDS read
+                else if (i < MF + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
     // epilogue.  The operands are swapped (weights as the MFMA's A, activations as its B), so in the 16x16 C/D
@@ -896,6 +1114,40 @@ static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpac
     }
     hipLaunchKernelGGL((k_conv3x3_sk<MODE, GT, NSPLIT>), dim3((G + GT - 1) / GT, N / 32), dim3(64 * NSPLIT), lds, st, act,
                        (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
+}
+
+// cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
+// runs the per-layer path)
+template <int GT>
+static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
+                            uint32_t* sync, uint32_t* err) {
+    constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
+    constexpr int lds_a = (ROWS + 1) * 528 + 16 * 35, lds_p = 8 * MF * 32 * (32 * 4 + 16);
+    constexpr int lds = lds_a > lds_p ? lds_a : lds_p;
+    static int capacity = -1;
+    if (capacity < 0) {
+        (void)hipFuncSetAttribute((const void*)k_tower_cl<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_tower_cl<GT>, 512, lds) != hipSuccess)
+            capacity = 0;
+        else
+            capacity = per_cu * prop.multiProcessorCount;
+    }
+    const int groups = (G + GT - 1) / GT;
+    const int grid = 64 * ((groups + 7) / 8);
+    if (grid > capacity || groups > kClusterMaxGroups) return false;
+    hipLaunchKernelGGL((k_tower_cl<GT>), dim3(grid), dim3(512), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err);
+    return true;
+}
+bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
+                          int G, uint32_t* sync, uint32_t* err) {
+    switch (boards_per_group) {
+        case 2: return tower_cl_launch<2>(st, X, H, wt, bias, G, sync, err);
+        case 4: return tower_cl_launch<4>(st, X, H, wt, bias, G, sync, err);
+        default: return false;
+    }
 }
 
 // the whole tower in one launch; x_in/x_out may alias.  geometry 0: 4 boards x (4 waves x 2 N-fragments),

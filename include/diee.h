@@ -91,6 +91,9 @@ typedef struct {
     double   tower_seconds;    /* HIP-event time of sampled fused-tower launches (k_tower)  */
     uint64_t tower_launches;
     double   tower_flops;
+    double   cluster_seconds;  /* HIP-event time of sampled cluster-tower launches (k_tower_cl, small batches) */
+    uint64_t cluster_launches;
+    double   cluster_flops;
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */
