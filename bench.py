@@ -117,6 +117,7 @@ def main():
 
     keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
+            "cluster_seconds", "cluster_launches", "cluster_flops",
             "fragments", "illegal_decodes"]
     if dist is not None:
         dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
@@ -145,14 +146,18 @@ def main():
                     "frac": a / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_sampled": launches / world,
                     "avg_launch_us": sec / max(launches, 1) * 1e6,
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
-                    "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"])}
-        # the tower of 38 3x3 convs is ~95 % of the GPU time; it runs as ONE fused launch (k_tower) while more
-        # than 200 games are alive and as 38 per-layer launches (k_conv3x3_sk) below that
+                    "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"])}
+        # the tower of 38 3x3 convs is ~90 % of the GPU time; it runs as ONE fused launch (k_tower16: activations in LDS)
+        # while more than 200 games are alive, as ONE cluster launch (k_tower_cl: 8-workgroup clusters per board group)
+        # at 128 games or fewer, and as 38 per-layer launches (k_conv3x3_sk) in between
         r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 200 boards)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
-        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; batches <= 200 boards)",
+        r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters, latency-bound; batches <= 128 boards)",
+                         tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"])
+        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; 128 < boards <= 200)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
-        dominant, other = (r_fused, r_layer) if tot["tower_seconds"] >= tot["conv_seconds"] else (r_layer, r_fused)
+        ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
+        dominant, other = ranked[0], ranked[1:]
         out = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,

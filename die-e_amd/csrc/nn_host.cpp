@@ -275,6 +275,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     hipStream_t st = e.stream;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
     const int tgeom = W.tower_geometry_for(G);
+    static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
     const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch (development)
     // the init block reads the states and builds the input planes itself (no separate planes kernel)
     if (!whole)
@@ -299,6 +300,9 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
             launch_conv3x3(st, 256, 1, W.actH.p, W.wl(2 + 2 * i), W.bl(2 + 2 * i), W.actX.p, W.actX.p, nullptr, G, 256);
         }
     }
+    if (trace_dispatch)
+        fprintf(stderr, "[diee] forward of %d boards: %s (fused geometry %d, conv variant table entries %zu / %zu)\n", G,
+                kind == 1 ? "fused tower" : kind == 2 ? "cluster tower" : "per-layer kernels", tgeom, W.tower_table.size(), W.cluster_table.size());
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind});
@@ -370,7 +374,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const auto saved_cl = W.cluster_table;
     if (variant >= 100 && variant <= 109) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
-    if (variant == 202 || variant == 204) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
+    if (variant == 201 || variant == 202 || variant == 204) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
@@ -394,6 +398,20 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
         for (int i = 0; i < 2048; ++i) if (h[2 * i + 1]) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
         std::sort(mhz.begin(), mhz.end());
         if (!mhz.empty()) fprintf(stderr, "[diee] fused tower in-kernel clock: median %.0f MHz (min %.0f, max %.0f) over %zu workgroups; %llu shader cycles\n", mhz[mhz.size() / 2], mhz.front(), mhz.back(), mhz.size(), h[0]);
+    }
+    if (getenv("DIEE_CLUSTER_CLOCK") && (variant == 201 || variant == 202 || variant == 204)) {   // diagnostic build: per-phase cycles of a cluster-tower layer
+        DevBuf<unsigned long long> dbg; dbg.ensure(8192);
+        HIPCHK(hipMemsetAsync(dbg.p, 0, 8192 * 8, st));
+        nn_set_tower_dbg(dbg.p);
+        const auto saved2 = W.cluster_table; W.cluster_table = {{1 << 30, variant - 200}};
+        nn_forward(e, e.tmp_a.p, G, (float*)e.tmp_b.p, (float*)e.tmp_c.p);
+        W.cluster_table = saved2; nn_set_tower_dbg(nullptr);
+        std::vector<unsigned long long> h(8192);
+        e.d2h(h.data(), dbg.p, (size_t)8192); e.sync();
+        static const char* names[6] = {"poll tile in", "stage (barrier)", "MFMA loop (barrier)", "partials (barrier)", "reduce + store", "end barrier"};
+        double sum[6] = {0, 0, 0, 0, 0, 0}; int nwg = 0;
+        for (int b2 = 0; b2 < 1024; ++b2) if (h[b2 * 8 + 2]) { ++nwg; for (int i = 0; i < 6; ++i) sum[i] += (double)h[b2 * 8 + i] / 35.0; }
+        for (int i = 0; i < 6 && nwg; ++i) fprintf(stderr, "[diee] cluster tower G=%d: %-20s %8.0f cycles / layer (mean of %d workgroups)\n", G, names[i], sum[i] / nwg, nwg);
     }
     nn_set_conv_variant(0);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);

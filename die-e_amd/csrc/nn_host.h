@@ -32,7 +32,7 @@ struct NetWeights {
     // boards per 8-workgroup cluster; tried in order, a batch no rule takes (or whose grid would not be co-resident)
     // runs per-layer kernels.  DIEE_TOWER_CL="max:boards,max:boards" overrides ("none" disables).
     struct ClusterRule { int max_games, boards_per_group; };
-    std::vector<ClusterRule> cluster_table = {{64, 2}, {128, 4}};
+    std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}};
     DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias

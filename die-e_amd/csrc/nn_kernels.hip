@@ -12,6 +12,7 @@
 //   * v_mfma_f32_32x32x16_bf16, 6 M-fragments x 1 N-fragment per wave: 96 accumulator registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 
 #include "bg_device.h"
 #include "launch.h"
@@ -368,14 +369,18 @@ constexpr int kClusterSpinLimit = 1 << 18;
 // device-coherent 16-byte accesses for data other workgroups exchange inside a launch: relaxed agent-scope atomics
 // (global_load/store_dwordx2 sc1) reach the coherent level themselves, so the handshake needs no L2-wide
 // write-back / invalidate (an agent-scope fence costs ~0.1 us per wave and serialises per XCD: measured 19 us per layer)
-__device__ __forceinline__ u32x4 ld_coherent16(const uint16_t* p) {
-    const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+// (16-byte forms: buffer_load/store_dwordx4 with aux 16 = sc1; the ready tags below are per 8-byte half, so nothing
+// depends on a 16-byte access being performed as one)
+typedef __attribute__((ext_vector_type(4))) unsigned int rb_u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coherent_rsrc(uint16_t* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_coherent16(uint16_t* p, u32x4 v) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ u32x4 ld_coherent16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const rb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    return u32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void st_coherent16(__amdgpu_buffer_rsrc_t r, int byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, r, byte_off, 0, 16);
 }
 
 // Ready flag carried by the data: activations are post-ReLU bf16, so their sign bits are free.  The output of layer w
@@ -392,12 +397,15 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
                                                   const float* __restrict__ bias,    // [38][256]
                                                   int M, int n_groups,
                                                   uint32_t* sync,                    // [n_groups] counters, 128 B apart, zero between launches
-                                                  uint32_t* err) {
+                                                  uint32_t* err, unsigned long long* dbg) {
     constexpr int NSPLIT = 8, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 512, KS = 18;
     constexpr int PRS = 32 * 4 + 16;
     static_assert(ROWS * 4 <= NT, "one output chunk per thread");
+    constexpr int TILE = ((ROWS + 1) * RS + 16 * 35 + 15) / 16 * 16;
+    constexpr int PART = NSPLIT * MF * 32 * PRS;
+    constexpr bool ALIAS = TILE + PART > 160 * 1024;        // 4 boards: the partial tiles must reuse the activation tile's LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* part = smem;                              // [8 waves][MF*32 rows][32] f32, aliases the activation tile
+    char* part = ALIAS ? smem : smem + TILE;        // [8 waves][MF*32 rows][32] f32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
@@ -427,15 +435,22 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
     // this thread's output chunk (row r, 8 channels) and its residual: the block input, kept in registers
     const int er = tid >> 2, ec8 = tid & 3, egr = row0 + er;
     const bool ework = tid < ROWS * 4 && egr < M;
-    const size_t eoff = (size_t)egr * 256 + nslice * 32 + ec8 * 8;
+    const int eoff = (egr * 256 + nslice * 32 + ec8 * 8) * 2;       // byte offset of the chunk in X / H
+    const __amdgpu_buffer_rsrc_t rX = coherent_rsrc(X, M * 512), rH = coherent_rsrc(H, M * 512);
     u32x4 resreg = {0u, 0u, 0u, 0u};
-    if (ework) resreg = *(const u32x4*)(X + eoff);
+    if (ework) resreg = ld_coherent16(rX, eoff);
     // a wait timed out, now or in an earlier launch (reported through err): stop waiting, finish the launch
     bool dead = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;
 
+#if DIEE_TOWER_ABLATE == 3
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;    // per-phase shader-clock sums over layers 2..36 (thread 0)
+#define CL_STAMP(i) { const unsigned long long tn = __builtin_readcyclecounter(); if (l >= 2 && l <= 36) ph[i] += tn - tprev; tprev = tn; }
+#else
+#define CL_STAMP(i)
+#endif
     for (int l = 0; l < 38; ++l) {
-        const uint16_t* in = (l & 1) ? H : X;
-        uint16_t* out = (l & 1) ? X : H;
+        const __amdgpu_buffer_rsrc_t in = (l & 1) ? rH : rX, out = (l & 1) ? rX : rH;
+        CL_STAMP(5)                                 // end-of-layer barrier
         const float4 bias_lo = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8);      // requested ahead of the epilogue
         const float4 bias_hi = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8 + 4);
         if (l == 1) {
@@ -451,34 +466,38 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
         }
         // ---- stage the activation tile; from layer 2 on the data is its own ready flag (see tag_of) ----
         {
-            constexpr int NCH = ROWS * CPR / NT;    // 16-byte chunks per thread: all requested before the first is stored
-            static_assert(ROWS * CPR % NT == 0, "whole chunks per thread");
+            constexpr int NCH = (ROWS * CPR + NT - 1) / NT;     // 16-byte chunks per thread: all requested before the first is stored
             u32x4 v[NCH];
             const uint32_t want = l >= 2 ? tag_of(l - 1) : 0u;
             for (int spins = 0;; ++spins) {
                 // all chunks are requested back to back (rows past the batch re-read its last row: no branch, no wait in between)
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const int gr = row0 + (tid + k * NT) / CPR;
-                    v[k] = ld_coherent16(in + (size_t)(gr < M ? gr : M - 1) * 256 + (tid % CPR) * 8);
+                    int gr = row0 + (tid + k * NT) / CPR;
+                    if (ROWS * CPR % NT != 0 && tid + k * NT >= ROWS * CPR) gr = row0;      // ragged last chunk: re-read, never stored
+                    v[k] = ld_coherent16(in, (gr < M ? gr : M - 1) * 512 + (tid % CPR) * 16);
                 }
                 uint32_t bad = 0u;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
                 if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
                 if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
+                __builtin_amdgcn_s_sleep(2);
             }
+            CL_STAMP(0)                             // tile polled in
 #pragma unroll
             for (int k = 0; k < NCH; ++k)
                 if (row0 + (tid + k * NT) / CPR >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 v[k][0] &= ~0x8000u; v[k][2] &= ~0x8000u;
-                *(u32x4*)(smem + ((tid + k * NT) / CPR) * RS + (tid % CPR) * 16) = v[k];
+                if (ROWS * CPR % NT == 0 || tid + k * NT < ROWS * CPR)
+                    *(u32x4*)(smem + ((tid + k * NT) / CPR) * RS + (tid % CPR) * 16) = v[k];
             }
         }
         if (tid < CPR + 3) *(u32x4*)(smem + ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};      // zero row
         __syncthreads();
+        CL_STAMP(1)                                 // tile staged (barrier)
 
         f32x16 acc[MF];
 #pragma unroll
@@ -502,7 +521,8 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        __syncthreads();                            // every wave is done reading the activation tile
+        if (ALIAS) __syncthreads();                 // every wave is done reading the activation tile
+        CL_STAMP(2)                                 // MFMA loop + barrier
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
@@ -511,6 +531,7 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
                 *(float*)(part + ((wave * MF * 32 + r) * PRS) + (lane & 31) * 4) = acc[f][i];
             }
         __syncthreads();
+        CL_STAMP(3)                                 // partial tiles written (barrier)
         if (ework) {
             float v[8] = {bias_lo.x, bias_lo.y, bias_lo.z, bias_lo.w, bias_hi.x, bias_hi.y, bias_hi.z, bias_hi.w};
 #pragma unroll
@@ -535,8 +556,9 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
             if (l & 1) resreg = o;                  // block output = next block's input
             const uint32_t tg = l < 37 ? tag_of(l) : 0u;             // the tower output itself leaves untagged
             o[0] |= tg; o[2] |= tg;
-            st_coherent16(out + eoff, o);
+            st_coherent16(out, eoff, o);
         }
+        CL_STAMP(4)                                 // reduce + store issued
         if (l == 0 || l == 37) {
             // first hand-over: signal through the counter once this workgroup's stores are acknowledged;
             // the second arrival round (end of launch) re-arms the counter for the next launch
@@ -547,9 +569,16 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
                 if (old == 15u) atomicExch(cnt, 0u);
             }
         } else {
-            __syncthreads();                        // partial tiles are consumed before the next tile is staged
+            // partial tiles are consumed before the next tile is staged over them; without aliasing the barrier still
+            // pays: it keeps the waves that have no output chunk from polling the next tile (and loading the memory
+            // system) while the others reduce and store
+            __syncthreads();
         }
     }
+#if DIEE_TOWER_ABLATE == 3
+    if (dbg && tid == 0)
+        for (int i = 0; i < 6; ++i) dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 // Large-batch variant: the whole 38-layer tower in ONE launch.  A workgroup owns 4 boards and all 256
@@ -1116,34 +1145,40 @@ static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpac
                        (const u32x4*)wpack, bias, res, out, out_v, G * 24, N);
 }
 
+static unsigned long long* g_tower_dbg = nullptr;     // diagnostic builds: per-workgroup clock stamps
+void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
+
 // cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
 // runs the per-layer path)
 template <int GT>
 static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
-    constexpr int lds_a = (ROWS + 1) * 528 + 16 * 35, lds_p = 8 * MF * 32 * (32 * 4 + 16);
-    constexpr int lds = lds_a > lds_p ? lds_a : lds_p;
+    constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = 8 * MF * 32 * (32 * 4 + 16);
+    constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
     static int capacity = -1;
     if (capacity < 0) {
         (void)hipFuncSetAttribute((const void*)k_tower_cl<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_tower_cl<GT>, 512, lds) != hipSuccess)
-            capacity = 0;
-        else
-            capacity = per_cu * prop.multiProcessorCount;
+        // one 512-thread workgroup per CU is always admitted (the occupancy API is not asked: with 160 KB of dynamic LDS
+        // it answers 0 under some runtimes), and no geometry here needs more than one per CU
+        int dev = 0, cus = 0;
+        capacity = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? cus : 0;
     }
     const int groups = (G + GT - 1) / GT;
     const int grid = 64 * ((groups + 7) / 8);
-    if (grid > capacity || groups > kClusterMaxGroups) return false;
-    hipLaunchKernelGGL((k_tower_cl<GT>), dim3(grid), dim3(512), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err);
+    if (grid > capacity || groups > kClusterMaxGroups) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "[diee] cluster tower <%d>: %d boards need %d resident workgroups, the device holds %d: using per-layer kernels\n", GT, G, grid, capacity);
+        told = true;
+        return false;
+    }
+    hipLaunchKernelGGL((k_tower_cl<GT>), dim3(grid), dim3(512), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg);
     return true;
 }
 bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err) {
     switch (boards_per_group) {
+        case 1: return tower_cl_launch<1>(st, X, H, wt, bias, G, sync, err);
         case 2: return tower_cl_launch<2>(st, X, H, wt, bias, G, sync, err);
         case 4: return tower_cl_launch<4>(st, X, H, wt, bias, G, sync, err);
         default: return false;
@@ -1164,8 +1199,6 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
     hipLaunchKernelGGL((k_tower<GT, NF, PF>), dim3((G + GT - 1) / GT), dim3(64 * (8 / NF)), lds, st, x_in,
                        (const u32x4*)wt, bias, x_out, G * 24);
 }
-static unsigned long long* g_tower_dbg = nullptr;     // diagnostic builds: per-workgroup clock stamps
-void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 
 template <int GT, int NW, int PF>
 static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include "bg_device.h"
@@ -227,7 +228,9 @@ void Engine::self_play(uint32_t n_games, uint32_t first_game_id, const diee_mcts
     // ---- timed region: every input is resident in HBM ----
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t n_live = n_games, step = 0;
+    const bool trace_steps = getenv("DIEE_TRACE_STEPS") != nullptr;      // development: batch size of every move-step
     while (n_live > 0 && (max_steps == 0 || step < max_steps)) {       // alpha_parallel.rs:129
+        if (trace_steps) fprintf(stderr, "[diee] move-step %u: %u games alive\n", step, n_live);
         launch_gather_roots(stream, Gm, S, n_live, first_game_id);
         mcts_run(*this, n_live, *cfg, seed, step, flags);               // :146
         launch_play_move(stream, T, Gm, n_live, step, PP);              // :164-224

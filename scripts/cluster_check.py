@@ -22,7 +22,7 @@ def engine(cl):
     return e
 
 ref = engine("none")
-cl = engine("64:2,128:4")
+cl = engine("32:1,64:2,128:4")
 cl4 = engine("128:4")
 for G in (1, 2, 3, 5, 16, 17, 33, 64, 65, 100, 128, 129):
     p0, v0 = ref.forward_t(states[:G])
@@ -37,7 +37,7 @@ for G in (7, 64, 128):
     print(f"G {G}: 20 repeated forwards identical: {same}", flush=True)
 for G in (2, 8, 16, 32, 48, 64, 80, 96, 128):
     row = [f"G {G:4d}"]
-    for v in (17, 5, 6, 202, 204):
+    for v in (17, 6, 201, 202, 204):
         try:
             us = ref.conv_bench(G, v, 100)
             row.append(f"v{v} fwd {us[2]:7.1f} us")

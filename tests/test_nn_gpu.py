@@ -138,3 +138,48 @@ def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
     p2, v2 = e.forward_t(states[::-1].copy())
     assert (p2[::-1] == p).all() and (v2[::-1] == v).all()
     e.close(); e0.close()
+
+
+def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
+    """small batches run the 38 tower layers in one launch, 8-workgroup clusters exchanging activations through
+    device-coherent tagged loads (k_tower_cl); per output element the arithmetic is the per-layer split-K kernel's,
+    so results are bit-identical, run after run, for every batch size (ragged groups included)"""
+    import diee_amd
+    from oracle.nn_ref import parse, forward_t
+    blob = diee_amd.random_weights(0)
+    states = oracle.random_walk_states(29, 6)[:200]
+    monkeypatch.setenv("DIEE_TOWER_CL", "none")
+    ref = diee_amd.Engine(0); ref.load_weights(blob)
+    monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4")
+    cl = diee_amd.Engine(0); cl.load_weights(blob)
+    monkeypatch.setenv("DIEE_TOWER_CL", "64:2")
+    cl2 = diee_amd.Engine(0); cl2.load_weights(blob)
+    monkeypatch.setenv("DIEE_TOWER_CL", "128:4")
+    cl4 = diee_amd.Engine(0); cl4.load_weights(blob)
+    for G in (1, 2, 3, 8, 9, 31, 32, 33, 63, 64):           # 1 / 2 boards per cluster vs per-layer 8-way split-K: exact
+        p0, v0 = ref.forward_t(states[:G])
+        for e in (cl, cl2, cl4):
+            p, v = e.forward_t(states[:G])
+            assert (p == p0).all() and (v == v0).all(), G
+    p128, v128 = cl.forward_t(states[:128])                   # 4 boards per cluster (per-layer path splits K 4 ways there)
+    p0, v0 = ref.forward_t(states[:128])
+    assert np.abs(p128 - p0).max() < 2e-5 and np.abs(v128 - v0).max() < 5e-3
+    for G in (65, 101, 127):                                  # rows do not depend on the batch around them
+        p, v = cl.forward_t(states[:G])
+        bad = np.where((p != p128[:G]).any(1) | (v != v128[:G]))[0]
+        assert len(bad) == 0, (G, bad[:16], float(np.abs(p - p128[:G]).max()), float(np.abs(p - p0[:G]).max()),
+                               float(np.abs(p128 - p0).max()))
+    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:32]))
+    assert np.abs(p128[:32] - rp).max() <= POLICY_ATOL and np.abs(v128[:32] - rv).max() <= VALUE_ATOL
+    # hand-offs under changing batch sizes and back-to-back launches: every run identical
+    rng = np.random.default_rng(5)
+    want = {}
+    for _ in range(150):
+        G = int(rng.integers(1, 129))
+        p, v = cl.forward_t(states[:G])
+        if G not in want:
+            want[G] = (p128[:G], v128[:G]) if G > 64 else ref.forward_t(states[:G])
+        assert (p == want[G][0]).all() and (v == want[G][1]).all(), G
+    p200, _ = cl.forward_t(states)                            # above the cluster range: per-layer kernels
+    assert (p200 == ref.forward_t(states)[0]).all()
+    for e in (ref, cl, cl2, cl4): e.close()
