@@ -148,13 +148,13 @@ def main():
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
                     "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"])}
         # the tower of 38 3x3 convs is ~90 % of the GPU time; it runs as ONE fused launch (k_tower16: activations in LDS)
-        # while more than 200 games are alive, as ONE cluster launch (k_tower_cl: 8-workgroup clusters per board group)
-        # at 128 games or fewer, and as 38 per-layer launches (k_conv3x3_sk) in between
-        r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 200 boards)",
+        # while more than 256 games are alive and as ONE cluster launch (k_tower_cl: 8-workgroup clusters per board group)
+        # at 256 games or fewer; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
+        r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 256 boards)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
-        r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters, latency-bound; batches <= 128 boards)",
+        r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"])
-        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; 128 < boards <= 200)",
+        r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; only when the other two are disabled)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
         dominant, other = ranked[0], ranked[1:]

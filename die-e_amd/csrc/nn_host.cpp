@@ -374,7 +374,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const auto saved_cl = W.cluster_table;
     if (variant >= 100 && variant <= 109) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
-    if (variant == 201 || variant == 202 || variant == 204) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
+    if (variant == 201 || variant == 202 || variant == 204 || variant == 208) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();
     for (int r = -2; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(a, st));
@@ -399,7 +399,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
         std::sort(mhz.begin(), mhz.end());
         if (!mhz.empty()) fprintf(stderr, "[diee] fused tower in-kernel clock: median %.0f MHz (min %.0f, max %.0f) over %zu workgroups; %llu shader cycles\n", mhz[mhz.size() / 2], mhz.front(), mhz.back(), mhz.size(), h[0]);
     }
-    if (getenv("DIEE_CLUSTER_CLOCK") && (variant == 201 || variant == 202 || variant == 204)) {   // diagnostic build: per-phase cycles of a cluster-tower layer
+    if (getenv("DIEE_CLUSTER_CLOCK") && (variant == 201 || variant == 202 || variant == 204 || variant == 208)) {   // diagnostic build: per-phase cycles of a cluster-tower layer
         DevBuf<unsigned long long> dbg; dbg.ensure(8192);
         HIPCHK(hipMemsetAsync(dbg.p, 0, 8192 * 8, st));
         nn_set_tower_dbg(dbg.p);

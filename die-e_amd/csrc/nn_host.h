@@ -21,18 +21,19 @@ struct NetWeights {
     // fused-tower dispatch: the first entry with G > min_games wins; batches below every entry run per-layer kernels.
     // Measured on MI355X (scripts/fwd_sweep*.py, scripts/tower_clock.py): 16x16x32 MFMA, 8 waves per workgroup (two per
     // SIMD: one wave's loads overlap the other's MFMAs: 79-81 % MFMA issue efficiency vs 62-67 % with one wave per SIMD),
-    // 4 boards per workgroup above 768 boards, 3 boards above 512, 2 boards above 200.  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
+    // 4 boards per workgroup above 768 boards, 3 boards above 512, 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
-    std::vector<TowerRule> tower_table = {{768, 8}, {512, 7}, {200, 3}};
+    std::vector<TowerRule> tower_table = {{768, 8}, {512, 7}, {256, 3}};
     int tower_geometry_for(int G) const {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
         return -1;
     }
     // cluster tower (k_tower_cl): batches of at most max_games boards run the 38 layers in one launch, boards_per_group
-    // boards per 8-workgroup cluster; tried in order, a batch no rule takes (or whose grid would not be co-resident)
-    // runs per-layer kernels.  DIEE_TOWER_CL="max:boards,max:boards" overrides ("none" disables).
+    // boards per 8-workgroup cluster (1, 2, 4: K split over 8 waves; 8: over 4 waves); tried in order, a batch no rule
+    // takes (or whose grid would not be co-resident) runs per-layer kernels.  Measured (scripts/cluster_check.py), forward
+    // of 16 / 64 / 128 / 200 / 256 boards: 121 / 149 / 207 / 318 / 346 us against 250 / 253 / 317 / 564 / 426 before.  DIEE_TOWER_CL="max:boards,max:boards" overrides ("none" disables).
     struct ClusterRule { int max_games, boards_per_group; };
-    std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}};
+    std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}, {256, 8}};
     DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias

@@ -21,7 +21,7 @@
 #define DIEE_TOWER_SCHED 1        // 1 = sched_group_barrier interleave of each k-step's loads between its MFMAs (0: loads issued as a block)
 #endif
 #ifndef DIEE_TOWER_ABLATE
-#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps
+#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights
 #endif
 
 namespace diee {
@@ -390,34 +390,37 @@ __device__ __forceinline__ void st_coherent16(__amdgpu_buffer_rsrc_t r, int byte
 // (w = 0 writes plain data over unknown leftovers, so that one hand-over uses the counter; w = 37 is the tower output.)
 __device__ __forceinline__ uint32_t tag_of(int w) { return (uint32_t)(((w >> 1) ^ w) & 1) << 15; }
 
-template <int GT>
-__global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                       // [M][256] bf16: init block output in, tower output out
-                                                  uint16_t* H,                       // [M][256] bf16 scratch (conv1 outputs)
-                                                  const u32x4* __restrict__ wt,      // [38][8][144][64] x 16 B
-                                                  const float* __restrict__ bias,    // [38][256]
-                                                  int M, int n_groups,
-                                                  uint32_t* sync,                    // [n_groups] counters, 128 B apart, zero between launches
-                                                  uint32_t* err, unsigned long long* dbg) {
-    constexpr int NSPLIT = 8, ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 512, KS = 18;
+template <int GT, int NSPLIT>
+__global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,               // [M][256] bf16: init block output in, tower output out
+                                                          uint16_t* H,               // [M][256] bf16 scratch (conv1 outputs)
+                                                          const u32x4* __restrict__ wt,      // [38][8][144][64] x 16 B
+                                                          const float* __restrict__ bias,    // [38][256]
+                                                          int M, int n_groups,
+                                                          uint32_t* sync,            // [n_groups] counters, 128 B apart, zero between launches
+                                                          uint32_t* err, unsigned long long* dbg) {
+    constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
+    constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
+    constexpr int PF = 18;                          // weight fragments in flight per wave
     constexpr int PRS = 32 * 4 + 16;
-    static_assert(ROWS * 4 <= NT, "one output chunk per thread");
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 35 + 15) / 16 * 16;
     constexpr int PART = NSPLIT * MF * 32 * PRS;
-    constexpr bool ALIAS = TILE + PART > 160 * 1024;        // 4 boards: the partial tiles must reuse the activation tile's LDS
+    constexpr bool ALIAS = TILE + PART > 160 * 1024;        // the partial tiles must reuse the activation tile's LDS
+    constexpr int CH = (ROWS * 4 + NT - 1) / NT;    // output chunks (row, 8 channels) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* part = ALIAS ? smem : smem + TILE;        // [8 waves][MF*32 rows][32] f32
+    char* part = ALIAS ? smem : smem + TILE;        // [NSPLIT waves][MF*32 rows][32] f32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int nslice = j & 7, grp = xcd + 8 * (j >> 3);
+    const int nslice = j & 7, grp = xcd + 8 * (j >> 3);             // a whole cluster on one XCD (measured 5-8 % faster than
+                                                                    // slice s of every group on XCD s, which would stream 1/8 of the weights per XCD)
     if (grp >= n_groups) return;
     const int row0 = grp * ROWS;
     uint32_t* cnt = sync + grp * 32;
 
     const u32x4* wp = wt + ((size_t)nslice * 144 + wave * KS) * 64 + lane;
-    u32x4 bq[KS];
+    u32x4 bq[PF];
 #pragma unroll
-    for (int i = 0; i < KS; ++i) bq[i] = wp[i * 64];
+    for (int i = 0; i < PF; ++i) bq[i] = wp[i * 64];
 
     int base[9][MF];
 #pragma unroll
@@ -429,30 +432,37 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
             const int dy = t / 3 - 1, dx = t % 3 - 1;
             const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
             const int src = ok ? R + 6 * dy + dx : ROWS;
-            base[t][f] = src * RS + (lane >> 5) * 16 + wave * 2 * 32;     // this wave's 2 channel steps
+            base[t][f] = src * RS + (lane >> 5) * 16 + wave * (16 / NSPLIT) * 32;     // this wave's channel steps
         }
     }
-    // this thread's output chunk (row r, 8 channels) and its residual: the block input, kept in registers
-    const int er = tid >> 2, ec8 = tid & 3, egr = row0 + er;
-    const bool ework = tid < ROWS * 4 && egr < M;
-    const int eoff = (egr * 256 + nslice * 32 + ec8 * 8) * 2;       // byte offset of the chunk in X / H
+    // this thread's output chunks (row, 8 channels) and their residual: the block input, kept in registers
     const __amdgpu_buffer_rsrc_t rX = coherent_rsrc(X, M * 512), rH = coherent_rsrc(H, M * 512);
-    u32x4 resreg = {0u, 0u, 0u, 0u};
-    if (ework) resreg = ld_coherent16(rX, eoff);
+    u32x4 resreg[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = tid + c * NT, gr = row0 + (i >> 2);
+        resreg[c] = u32x4{0u, 0u, 0u, 0u};
+        if (i < ROWS * 4 && gr < M) resreg[c] = ld_coherent16(rX, (gr * 256 + nslice * 32 + (i & 3) * 8) * 2);
+    }
     // a wait timed out, now or in an earlier launch (reported through err): stop waiting, finish the launch
     bool dead = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;
 
 #if DIEE_TOWER_ABLATE == 3
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;    // per-phase shader-clock sums over layers 2..36 (thread 0)
-#define CL_STAMP(i) { const unsigned long long tn = __builtin_readcyclecounter(); if (l >= 2 && l <= 36) ph[i] += tn - tprev; tprev = tn; }
+#define CL_STAMP(i) do { const unsigned long long tn = __builtin_readcyclecounter(); if (l >= 2 && l <= 36) ph[i] += tn - tprev; tprev = tn; } while (0);
 #else
-#define CL_STAMP(i)
+#define CL_STAMP(i) do {} while (0);
 #endif
     for (int l = 0; l < 38; ++l) {
         const __amdgpu_buffer_rsrc_t in = (l & 1) ? rH : rX, out = (l & 1) ? rX : rH;
         CL_STAMP(5)                                 // end-of-layer barrier
-        const float4 bias_lo = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8);      // requested ahead of the epilogue
-        const float4 bias_hi = *(const float4*)(bias + l * 256 + nslice * 32 + ec8 * 8 + 4);
+        float4 bias_lo[CH], bias_hi[CH];            // requested ahead of the epilogue
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = (tid + c * NT) < ROWS * 4 ? tid + c * NT : 0;
+            bias_lo[c] = *(const float4*)(bias + l * 256 + nslice * 32 + (i & 3) * 8);
+            bias_hi[c] = *(const float4*)(bias + l * 256 + nslice * 32 + (i & 3) * 8 + 4);
+        }
         if (l == 1) {
             // ---- first hand-over (H holds unknown leftovers): meet on the group's counter ----
             if (tid == 0 && !dead) {
@@ -466,33 +476,36 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
         }
         // ---- stage the activation tile; from layer 2 on the data is its own ready flag (see tag_of) ----
         {
-            constexpr int NCH = (ROWS * CPR + NT - 1) / NT;     // 16-byte chunks per thread: all requested before the first is stored
-            u32x4 v[NCH];
+            constexpr int NCH = (ROWS * CPR + NT - 1) / NT;     // 16-byte chunks per thread
+            constexpr int BATCH = NCH > 8 ? 8 : NCH;            // requested back to back before the first is stored
             const uint32_t want = l >= 2 ? tag_of(l - 1) : 0u;
-            for (int spins = 0;; ++spins) {
-                // all chunks are requested back to back (rows past the batch re-read its last row: no branch, no wait in between)
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    int gr = row0 + (tid + k * NT) / CPR;
-                    if (ROWS * CPR % NT != 0 && tid + k * NT >= ROWS * CPR) gr = row0;      // ragged last chunk: re-read, never stored
-                    v[k] = ld_coherent16(in, (gr < M ? gr : M - 1) * 512 + (tid % CPR) * 16);
+            for (int k0 = 0; k0 < NCH; k0 += BATCH) {
+                u32x4 v[BATCH];
+                for (int spins = 0;; ++spins) {
+                    // rows past the batch re-read its last row: no branch, no wait in between
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        int gr = row0 + (tid + (k0 + k) * NT) / CPR;
+                        if ((ROWS * CPR % NT != 0 || NCH % BATCH != 0) && tid + (k0 + k) * NT >= ROWS * CPR) gr = row0;      // ragged: re-read, never stored
+                        v[k] = ld_coherent16(in, (gr < M ? gr : M - 1) * 512 + (tid % CPR) * 16);
+                    }
+                    uint32_t bad = 0u;
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
+                    if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
+                    if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
                 }
-                uint32_t bad = 0u;
+                if (k0 == 0) CL_STAMP(0)            // first batch of the tile polled in
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
-                if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
-                if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            CL_STAMP(0)                             // tile polled in
-#pragma unroll
-            for (int k = 0; k < NCH; ++k)
-                if (row0 + (tid + k * NT) / CPR >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                v[k][0] &= ~0x8000u; v[k][2] &= ~0x8000u;
-                if (ROWS * CPR % NT == 0 || tid + k * NT < ROWS * CPR)
-                    *(u32x4*)(smem + ((tid + k * NT) / CPR) * RS + (tid % CPR) * 16) = v[k];
+                for (int k = 0; k < BATCH; ++k) {
+                    const int i = tid + (k0 + k) * NT;
+                    if (row0 + i / CPR >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
+                    v[k][0] &= ~0x8000u; v[k][2] &= ~0x8000u;
+                    if ((ROWS * CPR % NT == 0 && NCH % BATCH == 0) || i < ROWS * CPR)
+                        *(u32x4*)(smem + (i / CPR) * RS + (tid % CPR) * 16) = v[k];
+                }
             }
         }
         if (tid < CPR + 3) *(u32x4*)(smem + ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};      // zero row
@@ -507,14 +520,19 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
         bf16x8 a[2][MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
+#if DIEE_TOWER_ABLATE == 4
+        const u32x4* wn = wp + (size_t)(l & 1) * kTowerLayerStride;                  // timing experiment: weights stay L2-resident (wrong results)
+#else
         const u32x4* wn = wp + (size_t)(l < 37 ? l + 1 : l) * kTowerLayerStride;     // next layer's fragments (last layer: reloads its own, unused)
+#endif
+        const u32x4* wc = wp + (size_t)l * kTowerLayerStride;                        // this layer's
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
 #pragma unroll
             for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u]);
-            bq[u] = wn[u * 64];
+            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
+            bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];   // the ring runs ahead into the next layer
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
@@ -532,8 +550,11 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
             }
         __syncthreads();
         CL_STAMP(3)                                 // partial tiles written (barrier)
-        if (ework) {
-            float v[8] = {bias_lo.x, bias_lo.y, bias_lo.z, bias_lo.w, bias_hi.x, bias_hi.y, bias_hi.z, bias_hi.w};
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = tid + c * NT, er = i >> 2, ec8 = i & 3, egr = row0 + er;
+            if (i >= ROWS * 4 || egr >= M) continue;
+            float v[8] = {bias_lo[c].x, bias_lo[c].y, bias_lo[c].z, bias_lo[c].w, bias_hi[c].x, bias_hi[c].y, bias_hi[c].z, bias_hi[c].w};
 #pragma unroll
             for (int w = 0; w < NSPLIT; ++w) {
                 const float4 lo = *(const float4*)(part + (w * MF * 32 + er) * PRS + ec8 * 32);
@@ -543,8 +564,8 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
             if (l & 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[2 * k] += __uint_as_float(resreg[k] << 16);
-                    v[2 * k + 1] += __uint_as_float(resreg[k] & 0xffff0000u);
+                    v[2 * k] += __uint_as_float(resreg[c][k] << 16);
+                    v[2 * k + 1] += __uint_as_float(resreg[c][k] & 0xffff0000u);
                 }
             }
             u32x4 o;
@@ -553,10 +574,10 @@ __global__ __launch_bounds__(512) void k_tower_cl(uint16_t* X,                  
                 const float x0 = v[2 * k] > 0.0f ? v[2 * k] : 0.0f, x1 = v[2 * k + 1] > 0.0f ? v[2 * k + 1] : 0.0f;
                 o[k] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
             }
-            if (l & 1) resreg = o;                  // block output = next block's input
+            if (l & 1) resreg[c] = o;               // block output = next block's input
             const uint32_t tg = l < 37 ? tag_of(l) : 0u;             // the tower output itself leaves untagged
             o[0] |= tg; o[2] |= tg;
-            st_coherent16(out, eoff, o);
+            st_coherent16(out, (egr * 256 + nslice * 32 + ec8 * 8) * 2, o);
         }
         CL_STAMP(4)                                 // reduce + store issued
         if (l == 0 || l == 37) {
@@ -1150,16 +1171,16 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 
 // cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
 // runs the per-layer path)
-template <int GT>
+template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
-    constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = 8 * MF * 32 * (32 * 4 + 16);
+    constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * (32 * 4 + 16);
     constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
     static int capacity = -1;
     if (capacity < 0) {
-        (void)hipFuncSetAttribute((const void*)k_tower_cl<GT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        // one 512-thread workgroup per CU is always admitted (the occupancy API is not asked: with 160 KB of dynamic LDS
+        (void)hipFuncSetAttribute((const void*)k_tower_cl<GT, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        // one workgroup per CU is always admitted (the occupancy API is not asked: with 160 KB of dynamic LDS
         // it answers 0 under some runtimes), and no geometry here needs more than one per CU
         int dev = 0, cus = 0;
         capacity = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? cus : 0;
@@ -1172,15 +1193,16 @@ static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void
         told = true;
         return false;
     }
-    hipLaunchKernelGGL((k_tower_cl<GT>), dim3(grid), dim3(512), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg);
+    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid), dim3(64 * NSPLIT), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg);
     return true;
 }
 bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err) {
     switch (boards_per_group) {
-        case 1: return tower_cl_launch<1>(st, X, H, wt, bias, G, sync, err);
-        case 2: return tower_cl_launch<2>(st, X, H, wt, bias, G, sync, err);
-        case 4: return tower_cl_launch<4>(st, X, H, wt, bias, G, sync, err);
+        case 1: return tower_cl_launch<1, 8>(st, X, H, wt, bias, G, sync, err);
+        case 2: return tower_cl_launch<2, 8>(st, X, H, wt, bias, G, sync, err);
+        case 4: return tower_cl_launch<4, 8>(st, X, H, wt, bias, G, sync, err);
+        case 8: return tower_cl_launch<8, 4>(st, X, H, wt, bias, G, sync, err);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }

@@ -147,10 +147,12 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
     import diee_amd
     from oracle.nn_ref import parse, forward_t
     blob = diee_amd.random_weights(0)
-    states = oracle.random_walk_states(29, 6)[:200]
+    states = oracle.random_walk_states(29, 10)[:300]
+    assert len(states) == 300
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "768:8,512:7,256:3")
     monkeypatch.setenv("DIEE_TOWER_CL", "none")
     ref = diee_amd.Engine(0); ref.load_weights(blob)
-    monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4")
+    monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4,256:8")
     cl = diee_amd.Engine(0); cl.load_weights(blob)
     monkeypatch.setenv("DIEE_TOWER_CL", "64:2")
     cl2 = diee_amd.Engine(0); cl2.load_weights(blob)
@@ -180,6 +182,10 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
         if G not in want:
             want[G] = (p128[:G], v128[:G]) if G > 64 else ref.forward_t(states[:G])
         assert (p == want[G][0]).all() and (v == want[G][1]).all(), G
-    p200, _ = cl.forward_t(states)                            # above the cluster range: per-layer kernels
-    assert (p200 == ref.forward_t(states)[0]).all()
+    for G in (129, 200, 201, 255, 256):                      # 8 boards per cluster, K split over 4 waves like the per-layer
+        p, v = cl.forward_t(states[:G])                       # kernels of that size: exact
+        p0, v0 = ref.forward_t(states[:G])
+        assert (p == p0).all() and (v == v0).all(), G
+    p300, _ = cl.forward_t(states)                            # above the cluster range: the fused tower
+    assert (p300 == ref.forward_t(states)[0]).all()
     for e in (ref, cl, cl2, cl4): e.close()
