@@ -20,6 +20,9 @@
 #ifndef DIEE_TOWER_SCHED
 #define DIEE_TOWER_SCHED 1        // 1 = sched_group_barrier interleave of each k-step's loads between its MFMAs (0: loads issued as a block)
 #endif
+#ifndef DIEE_TOWER_BORDER
+#define DIEE_TOWER_BORDER 1      // 1 = the 4-board fused tower skips (tap, fragment) pairs that are all zero padding
+#endif
 #ifndef DIEE_TOWER_ABLATE
 #define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights
 #endif
@@ -737,7 +740,33 @@ __global__ __launch_bounds__(64 * (8 / NF)) void k_tower(const uint16_t* __restr
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int kTower16LayerStride = 16 * 72 * 64;        // u32x4 per layer (1.18 MB)
 
-template <bool RES, int GT, int NW, int PF>
+// Border-aware row order (4 boards per workgroup): a 16-row fragment holds the SAME four board positions of the four
+// boards, and the six fragments are the board's left column, right column, top and bottom edge (without corners) and
+// its two interior rows.  For a tap that points off the board the whole fragment is zero padding -- left column x
+// dx = -1, right column x dx = +1, top edge x dy = -1, bottom edge x dy = +1: 12 of the 54 (tap, fragment) pairs --
+// so its LDS read and MFMAs are not issued at all: 22 % fewer MFMAs for bit-identical results (the skipped products
+// are exact zeros).  The LDS tile itself keeps the [board*24 + position] layout; only the lane -> row map changes.
+__device__ __forceinline__ constexpr int border_pos(int f, int i) {      // position (6*y + x) number i of fragment f
+    return f == 0 ? 6 * i : f == 1 ? 6 * i + 5 : f == 2 ? 1 + i : f == 3 ? 19 + i : f == 4 ? 7 + i : 13 + i;
+}
+__device__ __forceinline__ constexpr bool border_skip(bool sp, int t, int f) {
+    return sp && ((f == 0 && t % 3 == 0) || (f == 1 && t % 3 == 2) || (f == 2 && t / 3 == 0) || (f == 3 && t / 3 == 2));
+}
+__device__ __forceinline__ constexpr int border_live(bool sp, int t, int mf) {   // fragments with work at tap t
+    int n = 0;
+    for (int f = 0; f < mf; ++f) n += border_skip(sp, t, f) ? 0 : 1;
+    return n;
+}
+// LDS row of lane-column n (0..15) of fragment f
+template <bool SP>
+__device__ __forceinline__ int tower_row(int f, int n) {
+    if (!SP) return 16 * f + n;
+    const int i = n & 3;
+    const int pos = f == 0 ? 6 * i : f == 1 ? 6 * i + 5 : f == 2 ? 1 + i : f == 3 ? 19 + i : f == 4 ? 7 + i : 13 + i;
+    return (n >> 2) * 24 + pos;
+}
+
+template <bool RES, int GT, int NW, int PF, bool SP = false>
 __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4* wp, const u32x4* wp_next,
                                               const float* __restrict__ bias, const uint32_t (&basep)[9][((GT * 24 + 15) / 16 + 1) / 2],
                                               u32x4 (&bq)[PF][16 / NW], int lane, int wave) {
@@ -751,14 +780,16 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
     // per-lane LDS addresses of the A fragments are < 64 KiB: two per register (keeps the 4-board geometry out of scratch)
     auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
 #pragma unroll
-    for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
+    for (int f = 0; f < MF; ++f)
+        if (!border_skip(SP, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
     for (int it = 0; it < (DIEE_TOWER_ABLATE == 1 ? 0 : 4); ++it) {
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
             const int csn = it * 2 + un / 9;                  // 8 on the very last step: reads padding, unused
 #pragma unroll
-            for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
+            for (int f = 0; f < MF; ++f)
+                if (!border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
             bf16x8 b[NFR];
 #pragma unroll
             for (int q = 0; q < NFR; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
@@ -772,19 +803,26 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-            for (int f = 0; f < MF; ++f)
+            for (int f = 0; f < MF; ++f) {
+                if (border_skip(SP, u % 9, f)) continue;           // this fragment x tap is all padding
 #pragma unroll
                 for (int q = 0; q < NFR; ++q)
                     acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);   // D = W^T x act^T
+            }
 #if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
 #else
             // interleave this k-step's loads between its MFMAs instead of issuing them as a block in front
+            {
+                constexpr int dummy = 0; (void)dummy;
+                const int n_mfma = border_live(SP, u % 9, MF) * NFR, n_lds = border_live(SP, un % 9, MF);
 #pragma unroll
-            for (int i = 0; i < MF * NFR; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-                if (i < MF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // 1 LDS read
-                else if (i < MF + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                for (int i = 0; i < MF * NFR; ++i) {
+                    if (i >= n_mfma) break;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+                    if (i < n_lds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
+                    else if (i < n_lds + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -799,7 +837,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
         const float4 bv = *(const float4*)(bias + n0);
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int r = 16 * f + (lane & 15);
+            const int r = tower_row<SP>(f, lane & 15);
             if (ROWS % 16 != 0 && r >= ROWS) continue;
             const int off = r * 528 + n0 * 2;
             float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
@@ -824,6 +862,7 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
                                                     unsigned long long* dbg /* clock stamps, diagnostic builds only */) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, RS = 528, NT = 64 * NW, NFR = 16 / NW;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
+    constexpr bool SP = GT == 4 && DIEE_TOWER_BORDER != 0;       // border-aware row order (see border_skip)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tx = smem;
     char* th = smem + TILE;
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         for (int h = 0; h < (MF + 1) / 2; ++h) basep[t][h] = 0;
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
-        const int R = 16 * f + (lane & 15);
+        const int R = tower_row<SP>(f, lane & 15);
         const int p = R % 24, y = p / 6, x = p % 6;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -872,8 +911,8 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTower16LayerStride;
         const u32x4* w2 = w1 + kTower16LayerStride;
         const u32x4* w3 = blk < 18 ? w2 + kTower16LayerStride : w2;
-        tower_layer16<false, GT, NW, PF>(tx, th, w1, w2, bias + (2 * blk) * 256, basep, bq, lane, wave);
-        tower_layer16<true, GT, NW, PF>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, basep, bq, lane, wave);
+        tower_layer16<false, GT, NW, PF, SP>(tx, th, w1, w2, bias + (2 * blk) * 256, basep, bq, lane, wave);
+        tower_layer16<true, GT, NW, PF, SP>(th, tx, w2, w3, bias + (2 * blk + 1) * 256, basep, bq, lane, wave);
     }
     if (DIEE_TOWER_ABLATE == 3 && dbg && tid == 0) {      // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
         dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;

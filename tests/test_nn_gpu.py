@@ -115,7 +115,26 @@ def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("geom", [3, 4, 5, 7, 8])
+def test_border_aware_fragments_are_bit_identical(oracle, monkeypatch):
+    """the 4-board fused tower orders its 16-row fragments by board region (left / right column, top / bottom edge,
+    interior) and does not issue the (tap, fragment) pairs that are all zero padding: same bits as the dense order"""
+    import diee_amd
+    blob = diee_amd.random_weights(0)
+    states = oracle.random_walk_states(33, 12)[:1001]           # ragged: last workgroup has one board
+    assert len(states) == 1001
+    out = []
+    for geom in (8, 6, 5, 9):                                   # 4 boards (8 waves PF 3 / 6, 4 waves) vs 3 boards dense
+        monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
+        e = diee_amd.Engine(0); e.load_weights(blob)
+        out.append(e.forward_t(states)); out.append(e.forward_t(states[:7]))
+        e.close()
+    for k in range(2, len(out), 2):
+        assert (out[k][0] == out[0][0]).all() and (out[k][1] == out[0][1]).all()
+        assert (out[k + 1][0] == out[1][0]).all() and (out[k + 1][1] == out[1][1]).all()
+    assert (out[1][0] == out[0][0][:7]).all()
+
+
+@pytest.mark.parametrize("geom", [3, 4, 5, 6, 7, 8])
 def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
     """the fused tower on v_mfma_f32_16x16x32_bf16 (2 / 3 / 4 boards per workgroup, 4 or 8 waves): same network, different
     MFMA shape, so equal to the 32x32x16 kernels up to fp32 summation order, and within the stated tolerance of fp32"""
@@ -149,7 +168,7 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(29, 10)[:300]
     assert len(states) == 300
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "768:8,512:7,256:3")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "704:8,416:6,256:3")
     monkeypatch.setenv("DIEE_TOWER_CL", "none")
     ref = diee_amd.Engine(0); ref.load_weights(blob)
     monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4,256:8")
