@@ -408,7 +408,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
         W.cluster_table = saved2; nn_set_tower_dbg(nullptr);
         std::vector<unsigned long long> h(8192);
         e.d2h(h.data(), dbg.p, (size_t)8192); e.sync();
-        static const char* names[6] = {"poll tile in", "stage (barrier)", "MFMA loop (barrier)", "partials (barrier)", "reduce + store", "end barrier"};
+        static const char* names[6] = {"poll tile in", "stage (barrier)", "MFMA loop (+ barrier)", "partials (barrier)", "reduce / epilogue + store", "end barrier"};
         double sum[6] = {0, 0, 0, 0, 0, 0}; int nwg = 0;
         for (int b2 = 0; b2 < 1024; ++b2) if (h[b2 * 8 + 2]) { ++nwg; for (int i = 0; i < 6; ++i) sum[i] += (double)h[b2 * 8 + i] / 35.0; }
         for (int i = 0; i < 6 && nwg; ++i) fprintf(stderr, "[diee] cluster tower G=%d: %-20s %8.0f cycles / layer (mean of %d workgroups)\n", G, names[i], sum[i] / nwg, nwg);

@@ -23,6 +23,12 @@
 #ifndef DIEE_TOWER_BORDER
 #define DIEE_TOWER_BORDER 1      // 1 = the 4-board fused tower skips (tap, fragment) pairs that are all zero padding
 #endif
+#ifndef DIEE_CL_PD
+#define DIEE_CL_PD 0              // cluster tower: LDS prefetch distance in k-steps (0 = by geometry)
+#endif
+#ifndef DIEE_CL_ABLATE
+#define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
+#endif
 #ifndef DIEE_TOWER_ABLATE
 #define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights
 #endif
@@ -368,6 +374,11 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_conv3x3_sk(const uint16_t* __re
 // resident at once (the launcher checks the occupancy); a wait is bounded and reports through `err` instead of hanging.
 constexpr int kTowerLayerStride = 8 * 144 * 64;          // u32x4 per layer (1.18 MB)
 constexpr int kClusterSpinLimit = 1 << 18;
+#ifndef DIEE_CL_PRS
+#define DIEE_CL_PRS 144
+#endif
+// partial-tile row stride (bytes); 160 (half-waves of a C-layout store on disjoint bank halves) measured no faster
+constexpr int kClusterPartStride = DIEE_CL_PRS;
 
 // device-coherent 16-byte accesses for data other workgroups exchange inside a launch: relaxed agent-scope atomics
 // (global_load/store_dwordx2 sc1) reach the coherent level themselves, so the handshake needs no L2-wide
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
-    constexpr int PRS = 32 * 4 + 16;
+    constexpr int PRS = kClusterPartStride;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 35 + 15) / 16 * 16;
     constexpr int PART = NSPLIT * MF * 32 * PRS;
     constexpr bool ALIAS = TILE + PART > 160 * 1024;        // the partial tiles must reuse the activation tile's LDS
@@ -520,9 +531,16 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
-        bf16x8 a[2][MF];
+        // A fragments are read PD k-steps ahead of their MFMAs.  Distances of 2 .. 8 (-DDIEE_CL_PD=n) measured no faster
+        // than 1 at any geometry: the loop is bound by the weight stream (timing builds -DDIEE_CL_ABLATE=1 / 2 / 3: at one
+        // board per cluster the loop costs 1.35 us per layer, 0.8 us of it vanish without the weight loads; the partial
+        // exchange costs 0.13 - 0.84 us), not by LDS latency.
+        constexpr int PD = DIEE_CL_PD > 0 ? DIEE_CL_PD : 1, NB = PD + 1;
+        bf16x8 a[NB][MF];
 #pragma unroll
-        for (int f = 0; f < MF; ++f) a[0][f] = *(const bf16x8*)(smem + base[0][f]);
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) a[d][f] = *(const bf16x8*)(smem + base[d % 9][f] + (d / 9) * 32);
 #if DIEE_TOWER_ABLATE == 4
         const u32x4* wn = wp + (size_t)(l & 1) * kTowerLayerStride;                  // timing experiment: weights stay L2-resident (wrong results)
 #else
@@ -530,27 +548,30 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
 #endif
         const u32x4* wc = wp + (size_t)l * kTowerLayerStride;                        // this layer's
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
-            const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
+        for (int u = 0; u < (DIEE_CL_ABLATE == 1 ? 0 : KS); ++u) {
+            const int un = u + PD;
+            if (un < KS) {
 #pragma unroll
-            for (int f = 0; f < MF; ++f) a[nxt][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+                for (int f = 0; f < MF; ++f) a[un % NB][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+            }
             const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
-            bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];   // the ring runs ahead into the next layer
+            if (DIEE_CL_ABLATE != 3) bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];   // the ring runs ahead into the next layer
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][f], b, acc[f], 0, 0, 0);
+            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NB][f], b, acc[f], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
         if (ALIAS) __syncthreads();                 // every wave is done reading the activation tile
         CL_STAMP(2)                                 // MFMA loop + barrier
 #pragma unroll
-        for (int f = 0; f < MF; ++f)
+        for (int f = 0; f < (DIEE_CL_ABLATE == 2 ? 0 : MF); ++f)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
                 *(float*)(part + ((wave * MF * 32 + r) * PRS) + (lane & 31) * 4) = acc[f][i];
             }
+        if (DIEE_CL_ABLATE == 2) { float sink = 0.0f; for (int f = 0; f < MF; ++f) for (int i = 0; i < 16; ++i) sink += acc[f][i]; if (sink == 12345.678f) part[0] = 1; }
         __syncthreads();
         CL_STAMP(3)                                 // partial tiles written (barrier)
 #pragma unroll
@@ -559,7 +580,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             if (i >= ROWS * 4 || egr >= M) continue;
             float v[8] = {bias_lo[c].x, bias_lo[c].y, bias_lo[c].z, bias_lo[c].w, bias_hi[c].x, bias_hi[c].y, bias_hi[c].z, bias_hi[c].w};
 #pragma unroll
-            for (int w = 0; w < NSPLIT; ++w) {
+            for (int w = 0; w < (DIEE_CL_ABLATE == 2 ? 0 : NSPLIT); ++w) {
                 const float4 lo = *(const float4*)(part + (w * MF * 32 + er) * PRS + ec8 * 32);
                 const float4 hi = *(const float4*)(part + (w * MF * 32 + er) * PRS + ec8 * 32 + 16);
                 v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
@@ -1214,7 +1235,7 @@ template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
-    constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * (32 * 4 + 16);
+    constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
     static int capacity = -1;
     if (capacity < 0) {
