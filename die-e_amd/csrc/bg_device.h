@@ -137,7 +137,10 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
     const bool dbl = hi == lo;
 
     // board bytes to LDS (per-lane byte reads later) and occupancy ballots
-    if (lane < 8) ((uint32_t*)sc->pts)[lane] = s.w[lane];
+    if (lane == 0) {                                             // constant indices: `s` stays in registers
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ((uint32_t*)sc->pts)[i] = s.w[i];
+    }
     __syncthreads();
     int v = 0;
     if (lane < 24) v = (int)(int8_t)sc->pts[lane] * player;      // own-signed count
@@ -328,23 +331,25 @@ __device__ __forceinline__ uint32_t bg_decode_dev(int r0, int r1, int player, ui
     return single ? pack_play(f1, t1, kNoMove, kNoMove) : pack_play(f1, t1, f2, t2);
 }
 
-// byte-wise add of a small delta to one point of a board held as 6 words (no carries across bytes)
+// byte-wise add of a small delta to one point of a board held as 6 words (no carries across bytes).
+// Every word is rewritten through a mask: a conditional `if (word == i) w[i] = ...` chain is turned by the compiler
+// into ONE dynamically indexed read-modify-write, which puts the state into scratch memory (a global-memory round
+// trip per access; measured: half of k_expand's time).
 __device__ __forceinline__ void pts_add(uint32_t (&w)[8], int point, int delta) {
+    const int wi = point >> 2, sh = 8 * (point & 3);
+    const uint32_t d = ((uint32_t)delta & 0xffu) << sh;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        if ((point >> 2) == i) {
-            const int sh = 8 * (point & 3);
-            const uint32_t b = (uint32_t)((int)(int8_t)(w[i] >> sh) + delta) & 0xffu;
-            w[i] = (w[i] & ~(0xffu << sh)) | (b << sh);
-        }
+        const uint32_t m = wi == i ? 0xffu << sh : 0u;
+        w[i] = (w[i] & ~m) | ((w[i] + d) & m);      // the byte's own sum; carries out of it fall outside the mask
     }
 }
 __device__ __forceinline__ int pts_get(const uint32_t (&w)[8], int point) {
-    int r = 0;
+    const int wi = point >> 2;
+    uint32_t x = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if ((point >> 2) == i) r = (int)(int8_t)(w[i] >> (8 * (point & 3)));
-    return r;
+    for (int i = 0; i < 6; ++i) x |= wi == i ? w[i] : 0u;
+    return (int)(int8_t)(x >> (8 * (point & 3)));
 }
 
 // get_next_state for one (from,to), backgammon_logic.rs:467-517
