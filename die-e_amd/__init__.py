@@ -40,7 +40,7 @@ EXPORTS = [
     "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
     "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
-    "diee_bg_planes", "diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench",
+    "diee_bg_planes", "diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library(path=None):
     L.diee_probe_f32.argtypes = [vp, vp, vp, u32, vp, vp, vp]; L.diee_probe_f32.restype = C.c_int
     L.diee_probe_dice.argtypes = [vp, u64, vp, u32, vp, vp]; L.diee_probe_dice.restype = C.c_int
     L.diee_dev_conv_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]; L.diee_dev_conv_bench.restype = C.c_int
+    L.diee_dev_rules_bench.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp]; L.diee_dev_rules_bench.restype = C.c_int
     if path is None:
         _lib = L
     return L
@@ -243,6 +244,13 @@ class Engine:
         a, b, f = C.c_float(0), C.c_float(0), C.c_float(0)
         self._chk(self._L.diee_dev_conv_bench(self._h, G, variant, reps, C.byref(a), C.byref(b), C.byref(f)))
         return a.value, b.value, f.value
+
+    def rules_bench(self, states, reps=20):
+        """device time (us) of one get_valid_moves launch over resident states, mean plays per state"""
+        s = _states(states)
+        us, k = C.c_float(0), C.c_float(0)
+        self._chk(self._L.diee_dev_rules_bench(self._h, s.ctypes.data, len(s), reps, C.byref(us), C.byref(k)))
+        return us.value, k.value
 
     # ---- search ------------------------------------------------------------------------------
     def alpha_mcts_parallel(self, states, cfg, seed=0, step=0, game_ids=None, rounds=None, ref_quirks=True):

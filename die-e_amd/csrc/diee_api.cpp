@@ -164,6 +164,14 @@ diee_status diee_dev_conv_bench(diee_ctx* c, int G, int variant, int reps, float
     API_END(c)
 }
 
+diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint32_t n, int reps, float* us_legal_moves,
+                                 float* mean_plays) {
+    API_BEGIN(c)
+    if (!states || !n || reps <= 0 || !us_legal_moves || !mean_plays) throw EngineError(DIEE_ERR_ARG, "bad arguments");
+    c->rules_bench(states, n, reps, us_legal_moves, mean_plays);
+    API_END(c)
+}
+
 void diee_free_fragments(diee_fragments* f) {
     if (!f) return;
     free(f->outcome); free(f->ps); free(f->state); free(f->game);

@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <cstring>
+#include <vector>
 
 #include "launch.h"
 
@@ -51,6 +52,35 @@ void Engine::legal_moves(const diee_bg_state* s, uint32_t n, int8_t* plays, uint
     d2h((uint8_t*)counts, tmp_c.p, (size_t)n * 4);
     sync();
     check_overflow();
+}
+
+// stand-alone timing of the get_valid_moves kernel, states resident (development probe)
+void Engine::rules_bench(const diee_bg_state* s, uint32_t n, int reps, float* us_legal_moves, float* mean_plays) {
+    HIPCHK(hipSetDevice(device));
+    const uint32_t cap = 160;
+    tmp_a.ensure((size_t)n * 32);
+    tmp_b.ensure((size_t)n * cap * 4 + 4);
+    tmp_c.ensure((size_t)n * 4);
+    h2d(tmp_a.p, (const uint8_t*)s, (size_t)n * 32);
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    for (int r = -2; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(a, stream));
+        launch_legal_moves(stream, tmp_a.p, n, (uint32_t*)tmp_b.p, cap, (uint32_t*)tmp_c.p, flags_dev.p);
+    }
+    HIPCHK(hipEventRecord(b, stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    std::vector<uint32_t> counts(n);
+    d2h((uint8_t*)counts.data(), tmp_c.p, (size_t)n * 4);
+    sync();
+    check_overflow();
+    double tot = 0;
+    for (uint32_t c : counts) tot += c;
+    *us_legal_moves = ms * 1e3f / (float)reps;
+    *mean_plays = (float)(tot / n);
 }
 
 void Engine::encode(const diee_bg_state* s, const int8_t* plays, uint32_t n, uint32_t* codes) {

@@ -52,6 +52,7 @@ public:
 
     // pure game functions
     void legal_moves(const diee_bg_state* s, uint32_t n, int8_t* plays, uint32_t cap, uint32_t* counts);
+    void rules_bench(const diee_bg_state* s, uint32_t n, int reps, float* us_legal_moves, float* mean_plays);
     void encode(const diee_bg_state* s, const int8_t* plays, uint32_t n, uint32_t* codes);
     void decode(const diee_bg_state* s, const uint32_t* codes, uint32_t n, int8_t* plays);
     void apply(diee_bg_state* s, const int8_t* plays, const uint8_t* dice, uint32_t n);
