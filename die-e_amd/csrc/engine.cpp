@@ -9,6 +9,7 @@
 namespace diee {
 
 void free_net(NetWeights*);
+void cluster_baton_register(int device, int delta);
 void free_search(SearchBufs*);
 
 Engine::Engine(int dev) : device(dev) {
@@ -18,10 +19,12 @@ Engine::Engine(int dev) : device(dev) {
     flags_dev.ensure(16);
     HIPCHK(hipMemsetAsync(flags_dev.p, 0, 16 * sizeof(uint32_t), stream));
     sync();
+    cluster_baton_register(device, +1);
 }
 
 Engine::~Engine() {
     (void)hipSetDevice(device);
+    if (stream) cluster_baton_register(device, -1);
     free_net(net);
     free_search(search);
     if (stream) (void)hipStreamDestroy(stream);

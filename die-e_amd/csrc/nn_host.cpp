@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "bg_device.h"
 #include "engine.h"
@@ -253,6 +254,21 @@ void nn_reserve(Engine& e, int G) {
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh)
+// The cluster tower's workgroups wait for each other inside the launch, so all of them must be resident together.
+// One launch never asks for more than the device holds, but two such launches from two contexts of this process on
+// the same GPU could each get half of the CUs and wait for the other half forever (until the bounded spins give up).
+// Contexts sharing a device therefore pass a per-device baton: a cluster launch waits for the previous one's event.
+// With one context per GPU (the documented use) the baton is never touched.
+namespace {
+struct ClusterBaton { std::mutex mu; hipEvent_t ev = nullptr; int engines = 0; };
+ClusterBaton g_baton[16];
+}
+void cluster_baton_register(int device, int delta) {
+    if (device < 0 || device >= 16) return;
+    std::lock_guard<std::mutex> lk(g_baton[device].mu);
+    g_baton[device].engines += delta;
+}
+
 // small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
 // would not be co-resident on this device: the caller runs the per-layer kernels.
 static bool cluster_tower(Engine& e, NetWeights& W, int G) {
@@ -261,6 +277,15 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G) {
         if (!W.cl_sync.p) {
             W.cl_sync.ensure((size_t)kClusterMaxGroups * 32);
             HIPCHK(hipMemsetAsync(W.cl_sync.p, 0, (size_t)kClusterMaxGroups * 32 * sizeof(uint32_t), e.stream));
+        }
+        ClusterBaton* bt = (e.device >= 0 && e.device < 16) ? &g_baton[e.device] : nullptr;
+        if (bt && bt->engines > 1) {
+            std::lock_guard<std::mutex> lk(bt->mu);
+            if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
+            else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
+            const bool ok = launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p);
+            if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
+            return ok;
         }
         return launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p);
     }

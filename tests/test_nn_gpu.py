@@ -208,3 +208,31 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
     p300, _ = cl.forward_t(states)                            # above the cluster range: the fused tower
     assert (p300 == ref.forward_t(states)[0]).all()
     for e in (ref, cl, cl2, cl4): e.close()
+
+
+def test_cluster_tower_two_contexts_on_one_gpu(oracle):
+    """two contexts of one process on the same GPU: their cluster-tower launches (each needs all its workgroups resident
+    together) are serialised by a per-device baton instead of starving each other; results stay exact"""
+    import threading
+    import diee_amd
+    blob = diee_amd.random_weights(0)
+    states = oracle.random_walk_states(17, 8)[:64]
+    a = diee_amd.Engine(0); a.load_weights(blob)
+    b = diee_amd.Engine(0); b.load_weights(blob)
+    want = {G: a.forward_t(states[:G]) for G in (48, 60)}
+    bad = []
+
+    def worker(e, G):
+        try:
+            for _ in range(120):
+                p, v = e.forward_t(states[:G])
+                if not ((p == want[G][0]).all() and (v == want[G][1]).all()):
+                    bad.append(G); return
+        except Exception as ex:                           # DIEE_ERR_HIP if a hand-over timed out
+            bad.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(a, 48)), threading.Thread(target=worker, args=(b, 60))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad, bad
+    a.close(); b.close()
