@@ -10,6 +10,7 @@ namespace diee {
 
 void free_net(NetWeights*);
 void cluster_baton_register(int device, int delta);
+void nn_reset_cluster(Engine& e);
 void free_search(SearchBufs*);
 
 Engine::Engine(int dev) : device(dev) {
@@ -37,6 +38,7 @@ void Engine::check_overflow() {
     if (f) {
         HIPCHK(hipMemsetAsync(flags_dev.p, 0, sizeof(uint32_t), stream));
         sync();
+        if (f & 4u) nn_reset_cluster(*this);                // the hand-over counters are in an unknown state: re-arm them
         if (f & 4u) throw EngineError(DIEE_ERR_HIP, "cluster tower: a workgroup handshake timed out (grid not co-resident?); set DIEE_TOWER_CL=none");
         throw EngineError(DIEE_ERR_CAPACITY, "device capacity overflow (sequence table / tree arena), flag=" + std::to_string(f));
     }

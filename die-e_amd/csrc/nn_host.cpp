@@ -269,6 +269,12 @@ void cluster_baton_register(int device, int delta) {
     g_baton[device].engines += delta;
 }
 
+// after a timed-out hand-over (reported as DIEE_ERR_HIP): zero the cluster counters so that later launches start clean
+void nn_reset_cluster(Engine& e) {
+    if (e.net && e.net->cl_sync.p)
+        (void)hipMemsetAsync(e.net->cl_sync.p, 0, (size_t)kClusterMaxGroups * 32 * sizeof(uint32_t), e.stream);
+}
+
 // small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
 // would not be co-resident on this device: the caller runs the per-layer kernels.
 static bool cluster_tower(Engine& e, NetWeights& W, int G) {
