@@ -66,6 +66,25 @@ def test_mcts_batch_bit_exact(eng, oracle, n, iters, pick, quirks):
         assert os_["terminal_hits"] > 0          # the terminal / stale-slot paths were exercised
 
 
+@pytest.mark.parametrize("n", [40, 100, 200, 300, 500, 720])
+def test_mcts_batch_bit_exact_across_tower_kernels(eng, oracle, n):
+    """one batch size per network path: cluster tower with 2 / 4 / 8 boards per cluster (40, 100, 200 roots), fused tower
+    with 2 boards per workgroup (300) and with 4 boards in border-aware order (500, 720): the search stays bit-exact"""
+    walk = oracle.random_walk_states(90, 40)
+    states = walk[50:50 + 4 * n:4]
+    assert len(states) == n
+    ocfg, gcfg = cfgs(oracle, 5)
+    ev, _ = gpu_eval(eng, oracle)
+    gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 7
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, ev, None, SEED, 1, gids, rds, 1)
+    r = eng.alpha_mcts_parallel(states, gcfg, SEED, 1, gids, rds, ref_quirks=True)
+    assert r["probs"].tobytes() == probs.tobytes(), np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max()
+    assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all()
+    gs, os_ = r["stats"], ostats.as_dict()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert gs[key] == os_[key], (key, gs[key], os_[key])
+
+
 @pytest.mark.parametrize("n,iters", [(4, 400), (2, 1600)])
 def test_deep_tree_configs_bit_exact(eng, oracle, n, iters):
     """BASELINE configs[2] (iterations=400) and configs[3] (iterations=1600 deep tree) at reduced N"""
