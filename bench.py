@@ -126,11 +126,11 @@ def main():
     if rank == 0:
         games = tot["games"]
         exp_per_game = tot["expansions"] / max(games, 1)
-        def pmc_traffic(name):
+        def pmc_traffic(name, fname="r01_pmc_traffic.json"):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction), at 1024 boards
+            # (profiles/r01_pmc_traffic*.json; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
             try:
-                doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
                     if k.startswith(name) and "hbm_side_bytes_per_launch_corrected" in v:
                         return v["hbm_side_bytes_per_launch_corrected"]
@@ -153,7 +153,8 @@ def main():
         r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 256 boards)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards)",
-                         tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"])
+                         tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],
+                         pmc_traffic("diee::k_tower_cl<1", "r01_pmc_traffic_32boards.json"))
         r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; only when the other two are disabled)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
