@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "bg_device.h"
+#include "nn_device.h"
 #include "launch.h"
 #include "search_types.h"
 
@@ -188,23 +189,26 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             }
         } else {
             node = S.leaf[slot];
-            v = S.nn_value[slot];
+            v = value_head(S.hv + (size_t)slot * 72, S.wv, lane);       // the value head's FC + tanh (nn_device.h)
             if (lane == 0) S.sel_value[slot] = v;
         }
-    } else if (slot == 0 && lane == 0) {
-        S.root_value0[0] = S.nn_value[0];
+    } else if (slot == 0) {
+        const float v0 = value_head(S.hv, S.wv, lane);
+        if (lane == 0) S.root_value0[0] = v0;
     }
     const uint32_t m0 = T.meta[base + node];
     if (do_expand && !(m0 & kDrained)) {
         const BgState st = load_state(&T.state[base + node]);
         const int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
         const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
-        const float* prow = S.policy + (size_t)slot * 1352;
+        const float* lrow = S.logits + (size_t)slot * 1352;
+        float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
+        softmax_consts(lrow, lane, smM, smInv);
         const float om = 1.0f - P.dir_eps;
         for (int j = lane; j < k; j += 64) {
             const uint32_t play = sc.ws.play[j];
             const uint32_t code = bg_encode_dev(r0, r1, play);
-            float p = prow[code];
+            float p = softmax_prob(lrow[code], smM, smInv);
             if (root) {                                      // apply_dirichlet: (1-eps)*P + eps*noise
                 const float x = om * p, y = P.dir_eps * S.noise[code];
                 p = x + y;

@@ -340,8 +340,14 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     }
     if (!whole) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
-    launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
+    if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
+}
+
+NetHeads nn_heads(Engine& e, int G) {
+    nn_reserve(e, G);
+    NetWeights& W = *e.net;
+    return NetHeads{W.logits.p, W.hv.p, W.wv.p};
 }
 
 // harvest sampled conv timings (call after a stream sync)

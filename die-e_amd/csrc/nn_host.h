@@ -62,7 +62,11 @@ struct NetWeights {
 };
 
 void nn_reserve(Engine& e, int G);
+// policy_dev == nullptr: stop after the policy FC and the head convs; the caller (the search) finishes the softmax and the
+// value head itself from nn_heads() with the functions of nn_device.h (same bits, one launch less per evaluation)
 void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev);
+struct NetHeads { const float* logits; const float* hv; const float* wv; };
+NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserved
 void nn_harvest(Engine& e, diee_stats* stats);
 void nn_reset_timing(Engine& e);
 void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward);

@@ -16,6 +16,7 @@
 
 #include "bg_device.h"
 #include "launch.h"
+#include "nn_device.h"
 
 #ifndef DIEE_TOWER_SCHED
 #define DIEE_TOWER_SCHED 1        // 1 = sched_group_barrier interleave of each k-step's loads between its MFMAs (0: loads issued as a block)
@@ -1150,42 +1151,17 @@ __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ h
     }
 }
 
-// softmax over the 1352 logits (nnet.rs:126-128) + value FC 72 -> 1 + tanh (nnet.rs:92-98): one wave per game
 __global__ __launch_bounds__(64) void k_softmax_value(const float* __restrict__ logits, const float* __restrict__ hv,
                                                       const float* __restrict__ wv /* [72] + bias */,
                                                       float* __restrict__ policy, float* __restrict__ value, int G) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= G) return;
     const float* lr = logits + (size_t)g * 1352;
-    float v[22];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 22; ++j) {
-        const int a = lane + 64 * j;
-        v[j] = a < 1352 ? lr[a] : -INFINITY;
-        mx = fmaxf(mx, v[j]);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 22; ++j) {
-        v[j] = lane + 64 * j < 1352 ? expf(v[j] - mx) : 0.0f;
-        sum += v[j];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int j = 0; j < 22; ++j) {
-        const int a = lane + 64 * j;
-        if (a < 1352) policy[(size_t)g * 1352 + a] = v[j] * inv;
-    }
-    float dot = 0.0f;
-    for (int k = lane; k < 72; k += 64) dot += hv[(size_t)g * 72 + k] * wv[k];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
-    if (lane == 0) value[g] = tanhf(dot + wv[72]);
+    float M, inv;
+    softmax_consts(lr, lane, M, inv);
+    for (int a = lane; a < 1352; a += 64) policy[(size_t)g * 1352 + a] = softmax_prob(lr[a], M, inv);
+    const float v = value_head(hv + (size_t)g * 72, wv, lane);
+    if (lane == 0) value[g] = v;
 }
 
 // ---- host launchers -----------------------------------------------------------------------------

@@ -26,7 +26,7 @@ struct SearchBufs {
     // slots
     DevBuf<BgState> roots, eval_states;
     DevBuf<uint32_t> game_id, round, leaf, sel, iter_flags;
-    DevBuf<float> sel_value, policy, nn_value, noise, root_value0;
+    DevBuf<float> sel_value, noise, root_value0;
     DevBuf<uint8_t> leaf_term;
     DevBuf<unsigned long long> counters;
     DevBuf<uint32_t> slot_cnt;
@@ -105,7 +105,6 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.used.ensure(sc);
         B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
-        B.policy.ensure((size_t)sc * 1352); B.nn_value.ensure(sc);
         B.noise.ensure(1352); B.root_value0.ensure(4); B.counters.ensure(CNT_COUNT); B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
     }
@@ -116,8 +115,9 @@ Tree tree_view(SearchBufs& B) {
     return Tree{B.visits.p, B.value.p, B.prior.p, B.parent.p, B.first_child.p, B.meta.p, B.nstate.p, B.used.p, B.node_cap};
 }
 Slots slots_view(Engine& e, SearchBufs& B) {
+    const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
-                 B.policy.p, B.nn_value.p, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
+                 H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
 }
 
 // alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round
@@ -133,12 +133,12 @@ void mcts_run(Engine& e, uint32_t n, const diee_mcts_cfg& cfg, uint64_t seed, ui
     HIPCHK(hipMemcpyAsync(B.noise.p, noise, sizeof noise, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));                                // `noise` is a stack buffer
     launch_init_roots(st, T, S, n);
-    nn_forward(e, B.eval_states.p, (int)n, B.policy.p, B.nn_value.p);  // forward_policy, alpha_mcts.rs:104
+    nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);        // forward_policy, alpha_mcts.rs:104 (softmax / tanh in k_expand)
     const SearchParams P{seed, cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
     launch_expand(st, T, S, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
-        nn_forward(e, B.eval_states.p, (int)n, B.policy.p, B.nn_value.p);   // alpha_mcts.rs:186
+        nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);       // alpha_mcts.rs:186
         launch_expand(st, T, S, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
     }
     launch_reduce_counters(st, S, n);

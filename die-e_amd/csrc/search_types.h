@@ -40,8 +40,9 @@ struct Slots {
     uint32_t* sel;          // [slots] selected_nodes_idxs (persists over iterations; 0xFFFFFFFF = initial)
     float* sel_value;       // [slots] NN value of sel
     uint8_t* leaf_term;     // [slots] leaf was terminal this iteration
-    float* policy;          // [slots][1352] ResNet softmax
-    float* nn_value;        // [slots]
+    const float* logits;    // [slots][1352] policy logits of this iteration's evaluation (nn_host's buffers)
+    const float* hv;        // [slots][72] value features
+    const float* wv;        // [73] value FC
     float* noise;           // [1352] Dirichlet sample of this move-step
     float* root_value0;     // [1] NN value of slot 0's root
     uint32_t* iter_flags;   // [2*(iterations)] any_selected, stale-initial count per iteration
