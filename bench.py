@@ -86,6 +86,10 @@ def main():
         import torch
         if torch.cuda.device_count() <= local_rank:   # a launcher that narrows HIP_VISIBLE_DEVICES to one GPU per rank
             dev = 0
+            if torch.cuda.device_count() * 1 < world and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+                # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
+                # which two processes on one GPU cannot promise each other
+                os.environ["DIEE_TOWER_CL"] = "none"
     eng = diee_amd.Engine(dev)                     # raises without a GPU: there is no CPU path
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
