@@ -22,9 +22,9 @@ struct NetWeights {
     // Measured on MI355X (scripts/fwd_sweep*.py, scripts/tower_clock.py): 16x16x32 MFMA, 8 waves per workgroup (two per
     // SIMD: one wave's loads overlap the other's MFMAs: 79-81 % MFMA issue efficiency vs 62-67 % with one wave per SIMD),
     // 4 boards per workgroup above 416 boards (border-aware fragment order: 22 % of the MFMAs are padding and not issued;
-    // 3 weight k-steps in flight above 704 boards, 6 below), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
+    // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
-    std::vector<TowerRule> tower_table = {{704, 8}, {416, 6}, {256, 3}};
+    std::vector<TowerRule> tower_table = {{928, 8}, {416, 6}, {256, 3}};
     int tower_geometry_for(int G) const {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
         return -1;

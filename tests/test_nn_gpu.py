@@ -168,7 +168,7 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(29, 10)[:300]
     assert len(states) == 300
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "704:8,416:6,256:3")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "928:8,416:6,256:3")
     monkeypatch.setenv("DIEE_TOWER_CL", "none")
     ref = diee_amd.Engine(0); ref.load_weights(blob)
     monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4,256:8")
