@@ -131,3 +131,13 @@ def test_f32_arithmetic_and_rng_bit_exact(eng, oracle):
     cnt = np.bincount(dice.reshape(-1), minlength=7)[1:]
     exp = dice.size / 6
     assert ((cnt - exp) ** 2 / exp).sum() < 30
+
+
+def test_rules_bench_probe_counts_the_same_plays(eng, oracle, states):
+    """diee_dev_rules_bench (the stand-alone timing of get_valid_moves over resident states): its mean play count is the
+    oracle's, and it reports a time"""
+    sub = states[:5000]
+    _, ref_counts = oracle.valid_moves_batch(sub, 256)
+    us, mean_plays = eng.rules_bench(sub, reps=3)
+    assert us > 0.0
+    assert abs(mean_plays - float(ref_counts.mean())) < 1e-3
