@@ -31,8 +31,9 @@ void nn_set_tower_dbg(unsigned long long* p);
 // cluster tower: 38 layers in one launch for small batches; `sync` = kClusterMaxGroups counters 128 B apart (zeroed),
 // `err` gets bit 2 set if a cluster wait timed out.  false = not launched (grid would not be co-resident).
 constexpr int kClusterMaxGroups = 64;
+// `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
 bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
-                          int G, uint32_t* sync, uint32_t* err);
+                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);

@@ -146,7 +146,8 @@ void Engine::load_weights(const float* blob, size_t n) {
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
-    if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;   // 0: keep init block / heads as separate launches
+    if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;
+    if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
         net->cluster_table.clear();
         std::string t(v);
@@ -249,6 +250,8 @@ void nn_reserve(Engine& e, int G) {
     if (G <= W.cap_games) return;
     const size_t Gp = (size_t)((G + 7) / 8 * 8), M = Gp * 24;
     W.x16.ensure(M * 16); W.actX.ensure(M * 256); W.actH.ensure(M * 256);
+    // the cluster tower's first tagged write into X relies on the sign bits it finds there being clear (plain data)
+    HIPCHK(hipMemsetAsync(W.actX.p, 0, M * 256 * sizeof(uint16_t), e.stream));
     W.hp.ensure(Gp * 768); W.hv.ensure(Gp * 72); W.logits.ensure(Gp * 1352);
     W.cap_games = (int)Gp;
 }
@@ -277,7 +280,8 @@ void nn_reset_cluster(Engine& e) {
 
 // small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
 // would not be co-resident on this device: the caller runs the per-layer kernels.
-static bool cluster_tower(Engine& e, NetWeights& W, int G) {
+static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states) {
+    const void* winit = W.wconv[0].p; const float* binit = W.bconv[0].p;
     for (const auto& r : W.cluster_table) {
         if (G > r.max_games) continue;
         if (!W.cl_sync.p) {
@@ -289,11 +293,11 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G) {
             std::lock_guard<std::mutex> lk(bt->mu);
             if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
             else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
-            const bool ok = launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p);
+            const bool ok = launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
             if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
             return ok;
         }
-        return launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p);
+        return launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
     }
     return false;
 }
@@ -308,27 +312,39 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     const int tgeom = W.tower_geometry_for(G);
     static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
     const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch (development)
-    // the init block reads the states and builds the input planes itself (no separate planes kernel)
-    if (!whole)
-        launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
-    // sampled timing of the 38-launch tower chain: one HIP-event pair per sampled forward (per-launch
-    // pairs cost ~4.6 us each and inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
+    // sampled timing of the tower: one HIP-event pair per sampled forward (per-launch pairs cost ~4.6 us each and
+    // inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int kind = 1;
-    if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
-    if (whole) {
-        launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
-                     W.hp.p, W.hv.p, G);
-    } else if (tgeom >= 0) {
-        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
-    } else if (cluster_tower(e, W, G)) {
-        kind = 2;                                                   // all 38 layers, 8-workgroup clusters per board group
-    } else {
-        kind = 0;
-        for (int i = 0; i < BLOCKS; ++i) {
-            launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
-            // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
-            launch_conv3x3(st, 256, 1, W.actH.p, W.wl(2 + 2 * i), W.bl(2 + 2 * i), W.actX.p, W.actX.p, nullptr, G, 256);
+    auto stamp0 = [&] { if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); } };
+    // the init block reads the states and builds the input planes itself (no separate planes kernel)
+    auto init_block = [&] {
+        launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+    };
+    bool done = false;
+    if (tgeom < 0 && !W.cluster_table.empty() && W.cluster_init) {
+        // small batches: init block + all 38 layers in ONE launch, 8-workgroup clusters per board group
+        stamp0();
+        if (cluster_tower(e, W, G, states_dev)) { kind = 2; done = true; }
+        else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
+    }
+    if (!done) {
+        if (!whole) init_block();
+        if (!ev0) stamp0();
+        if (whole) {
+            launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
+                         W.hp.p, W.hv.p, G);
+        } else if (tgeom >= 0) {
+            launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
+        } else if (cluster_tower(e, W, G, nullptr)) {
+            kind = 2;                                                   // (init block launched separately: DIEE_CLUSTER_INIT=0)
+        } else {
+            kind = 0;
+            for (int i = 0; i < BLOCKS; ++i) {
+                launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
+                // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
+                launch_conv3x3(st, 256, 1, W.actH.p, W.wl(2 + 2 * i), W.bl(2 + 2 * i), W.actX.p, W.actX.p, nullptr, G, 256);
+            }
         }
     }
     if (trace_dispatch)

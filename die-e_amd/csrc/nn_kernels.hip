@@ -412,7 +412,10 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                                                           const float* __restrict__ bias,    // [38][256]
                                                           int M, int n_groups,
                                                           uint32_t* sync,            // [n_groups] counters, 128 B apart, zero between launches
-                                                          uint32_t* err, unsigned long long* dbg) {
+                                                          uint32_t* err, unsigned long long* dbg,
+                                                          const BgState* __restrict__ states,    // non-null: the init block runs in here
+                                                          const u32x4* __restrict__ winit,   // [8][9][64] x 16 B (k_conv3x3<16,...>'s fragments)
+                                                          const float* __restrict__ binit) { // [256]
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
@@ -453,11 +456,75 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
     // this thread's output chunks (row, 8 channels) and their residual: the block input, kept in registers
     const __amdgpu_buffer_rsrc_t rX = coherent_rsrc(X, M * 512), rH = coherent_rsrc(H, M * 512);
     u32x4 resreg[CH];
+    if (states) {
+        // ---- init block in here (nnet.rs:64-67: conv 6 -> 256 + BN + ReLU), for ALL 256 channels of this cluster's boards:
+        // every workgroup of the cluster repeats it (331 k MAC per board) instead of waiting for a launch of its own and
+        // a hand-over.  Same fragments, same MFMA sequence as k_conv3x3<16, 0, ...>: the tile gets the same bits.
+        static_assert(!ALIAS || (TILE + (ROWS + 1) * 32 <= PART), "room for the input planes behind the activation tile");
+        char* pt = smem + TILE;                     // [ROWS + 1][16 channels] bf16 planes (6 real), 32-byte rows
+        for (int r = tid; r < ROWS + 1; r += NT) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < ROWS && row0 + r < M) {
+                const BgState st = states[(row0 + r) / 24];
+                const int p = (row0 + r) % 24;
+                uint32_t w[3];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int i = tid + c * NT, gr = row0 + (i >> 2);
-        resreg[c] = u32x4{0u, 0u, 0u, 0u};
-        if (i < ROWS * 4 && gr < M) resreg[c] = ld_coherent16(rX, (gr * 256 + nslice * 32 + (i & 3) * 8) * 2);
+                for (int c = 0; c < 3; ++c)
+                    w[c] = (uint32_t)f2bf(bg_plane_dev(st, 2 * c, p)) | ((uint32_t)f2bf(bg_plane_dev(st, 2 * c + 1, p)) << 16);
+                v = u32x4{w[0], w[1], w[2], 0u};
+            }
+            *(u32x4*)(pt + r * 32) = v;
+            *(u32x4*)(pt + r * 32 + 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        constexpr int NTW = 8 / NSPLIT;             // 32-channel N-tiles per wave
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const int nt = wave * NTW + q;
+            f32x16 acc[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf16x8 bw = __builtin_bit_cast(bf16x8, winit[((size_t)nt * 9 + t) * 64 + lane]);
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+                for (int f = 0; f < MF; ++f) {
+                    const int R = 32 * f + (lane & 31);
+                    const int p = R % 24, y = p / 6, x = p % 6;
+                    const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+                    const bf16x8 av = *(const bf16x8*)(pt + (ok ? R + 6 * dy + dx : ROWS) * 32 + (lane >> 5) * 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[f], 0, 0, 0);
+                }
+            }
+            const float bv = binit[nt * 32 + (lane & 31)];
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 32 * f + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    if (r >= ROWS) continue;
+                    float v = acc[f][i] + bv;
+                    v = (v > 0.0f && row0 + r < M) ? v : 0.0f;
+                    *(uint16_t*)(smem + r * RS + (nt * 32 + (lane & 31)) * 2) = f2bf(v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {              // the first block's residual: this workgroup's slice of the init output
+            const int i = tid + c * NT;
+            resreg[c] = u32x4{0u, 0u, 0u, 0u};
+            if (i < ROWS * 4) resreg[c] = *(const u32x4*)(smem + (i >> 2) * RS + (nslice * 32 + (i & 3) * 8) * 2);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = tid + c * NT, gr = row0 + (i >> 2);
+            resreg[c] = u32x4{0u, 0u, 0u, 0u};
+            if (i < ROWS * 4 && gr < M) resreg[c] = ld_coherent16(rX, (gr * 256 + nslice * 32 + (i & 3) * 8) * 2);
+        }
     }
     // a wait timed out, now or in an earlier launch (reported through err): stop waiting, finish the launch
     bool dead = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) != 0u;
@@ -490,7 +557,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             __syncthreads();                        // the tile loads below are device-coherent themselves
         }
         // ---- stage the activation tile; from layer 2 on the data is its own ready flag (see tag_of) ----
-        {
+        if (l > 0 || !states) {
             constexpr int NCH = (ROWS * CPR + NT - 1) / NT;     // 16-byte chunks per thread
             constexpr int BATCH = NCH > 8 ? 8 : NCH;            // requested back to back before the first is stored
             const uint32_t want = l >= 2 ? tag_of(l - 1) : 0u;
@@ -1209,7 +1276,7 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 // runs the per-layer path)
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
-                            uint32_t* sync, uint32_t* err) {
+                            uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
@@ -1229,16 +1296,17 @@ static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void
         told = true;
         return false;
     }
-    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid), dim3(64 * NSPLIT), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg);
+    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid), dim3(64 * NSPLIT), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg,
+                       (const BgState*)states, (const u32x4*)winit, binit);
     return true;
 }
 bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
-                          int G, uint32_t* sync, uint32_t* err) {
+                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
     switch (boards_per_group) {
-        case 1: return tower_cl_launch<1, 8>(st, X, H, wt, bias, G, sync, err);
-        case 2: return tower_cl_launch<2, 8>(st, X, H, wt, bias, G, sync, err);
-        case 4: return tower_cl_launch<4, 8>(st, X, H, wt, bias, G, sync, err);
-        case 8: return tower_cl_launch<8, 4>(st, X, H, wt, bias, G, sync, err);     // K split over 4 waves (one per SIMD)
+        case 1: return tower_cl_launch<1, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 2: return tower_cl_launch<2, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 4: return tower_cl_launch<4, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 8: return tower_cl_launch<8, 4>(st, X, H, wt, bias, G, sync, err, states, winit, binit);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }
