@@ -328,6 +328,12 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         if (cluster_tower(e, W, G, states_dev)) { kind = 2; done = true; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
+    if (!done && !whole && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
+        // large batches: init block + all 38 layers in one launch, activations stay in LDS
+        stamp0();
+        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G, states_dev, W.winit16.p, W.bconv[0].p);
+        done = true;
+    }
     if (!done) {
         if (!whole) init_block();
         if (!ev0) stamp0();

@@ -948,7 +948,10 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 template <int GT, int NW, int PF>
 __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict__ x_in, const u32x4* __restrict__ wt,
                                                     const float* __restrict__ bias, uint16_t* __restrict__ x_out, int M,
-                                                    unsigned long long* dbg /* clock stamps, diagnostic builds only */) {
+                                                    unsigned long long* dbg /* clock stamps, diagnostic builds only */,
+                                                    const BgState* __restrict__ states,   // non-null: the init block runs in here
+                                                    const u32x4* __restrict__ winit,      // [16][9][64] x 16 B (pack_init16)
+                                                    const float* __restrict__ binit) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, RS = 528, NT = 64 * NW, NFR = 16 / NW;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr bool SP = GT == 4 && DIEE_TOWER_BORDER != 0;       // border-aware row order (see border_skip)
@@ -965,11 +968,29 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
 #pragma unroll
         for (int q = 0; q < NFR; ++q) bq[i][q] = wp0[((size_t)q * 72 + i) * 64];
 
-    for (int i = tid; i < ROWS * 32; i += NT) {
-        const int r = i >> 5, ch = i & 31;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + r < M) v = *(const u32x4*)(x_in + (size_t)(row0 + r) * 256 + ch * 8);
-        *(u32x4*)(tx + r * RS + ch * 16) = v;
+    if (states) {
+        // input planes (backgammon_logic.rs:198-252) -> th, 64 bytes (32 channels, 6 real) per row; the init block below
+        for (int i = tid; i < ROWS * 4; i += NT) {
+            const int r = i >> 2, ch = i & 3;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ch == 0 && row0 + r < M) {
+                const BgState st = states[(row0 + r) / 24];
+                const int p = (row0 + r) % 24;
+                uint32_t w[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    w[c] = (uint32_t)f2bf(bg_plane_dev(st, 2 * c, p)) | ((uint32_t)f2bf(bg_plane_dev(st, 2 * c + 1, p)) << 16);
+                v = u32x4{w[0], w[1], w[2], 0u};
+            }
+            *(u32x4*)(th + r * RS + ch * 16) = v;
+        }
+    } else {
+        for (int i = tid; i < ROWS * 32; i += NT) {
+            const int r = i >> 5, ch = i & 31;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row0 + r < M) v = *(const u32x4*)(x_in + (size_t)(row0 + r) * 256 + ch * 8);
+            *(u32x4*)(tx + r * RS + ch * 16) = v;
+        }
     }
     for (int i = tid; i < 2 * 36; i += NT) {
         char* tl = i < 36 ? tx : th;
@@ -993,6 +1014,48 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         }
     }
     __syncthreads();
+    if (states) {
+        // ---- init block: conv 6 -> 256 + BN + ReLU (nnet.rs:64-67), th -> tx, one 32-channel k-step per tap; in the
+        // border-aware order the all-padding (tap, fragment) pairs are skipped here too ----
+        auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
+        f32x4 acc[MF][NFR];
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int q = 0; q < NFR; ++q) acc[f][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            bf16x8 b[NFR];
+#pragma unroll
+            for (int q = 0; q < NFR; ++q) b[q] = __builtin_bit_cast(bf16x8, winit[((size_t)(wave * NFR + q) * 9 + t) * 64 + lane]);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                if (border_skip(SP, t, f)) continue;
+                const bf16x8 av = *(const bf16x8*)(th + baddr(t, f));
+#pragma unroll
+                for (int q = 0; q < NFR; ++q) acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], av, acc[f][q], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) {
+            const int n0 = (wave * NFR + q) * 16 + (lane >> 4) * 4;
+            const float4 bv = *(const float4*)(binit + n0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int r = tower_row<SP>(f, lane & 15);
+                if (ROWS % 16 != 0 && r >= ROWS) continue;
+                float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
+                const bool live = row0 + r < M;
+                v0 = v0 > 0.0f && live ? v0 : 0.0f; v1 = v1 > 0.0f && live ? v1 : 0.0f;
+                v2 = v2 > 0.0f && live ? v2 : 0.0f; v3 = v3 > 0.0f && live ? v3 : 0.0f;
+                uint2 o;
+                o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                *(uint2*)(tx + r * RS + n0 * 2) = o;
+            }
+        }
+        __syncthreads();
+    }
     unsigned long long t0 = 0, r0 = 0;
     if (DIEE_TOWER_ABLATE == 3) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -1327,7 +1390,8 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
 }
 
 template <int GT, int NW, int PF>
-static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
+static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G,
+                           const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr) {
     static bool attr_set = false;
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
@@ -1336,7 +1400,7 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
         attr_set = true;
     }
     hipLaunchKernelGGL((k_tower16<GT, NW, PF>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
-                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg);
+                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit);
 }
 template <int GT, int NW, int PF>
 static void net16_launch(hipStream_t st, const Net16Params& P) {
@@ -1363,20 +1427,22 @@ void launch_net16(hipStream_t st, int geometry, const void* states, const void* 
 // geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9: 16x16x32 MFMA (wt16 = 16-column fragments):
 // 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 3, 7, 8)
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
-                  uint16_t* x_out, int G) {
+                  uint16_t* x_out, int G, const void* states, const void* winit16, const float* binit) {
     switch (geometry) {
         case 0: tower_launch<4, 2, 9>(st, x_in, wt, bias, x_out, G); break;
         case 1: tower_launch<2, 1, 18>(st, x_in, wt, bias, x_out, G); break;
-        case 2: tower16_launch<4, 4, 6>(st, x_in, wt16, bias, x_out, G); break;
-        case 5: tower16_launch<4, 4, 3>(st, x_in, wt16, bias, x_out, G); break;
-        case 3: tower16_launch<2, 8, 9>(st, x_in, wt16, bias, x_out, G); break;
-        case 6: tower16_launch<4, 8, 6>(st, x_in, wt16, bias, x_out, G); break;     // 4 boards, 8 waves (2 per SIMD)
-        case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G); break;
-        case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G); break;
-        case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G); break;
-        default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G); break;
+        case 2: tower16_launch<4, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 5: tower16_launch<4, 4, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 3: tower16_launch<2, 8, 9>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 6: tower16_launch<4, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;     // 4 boards, 8 waves (2 per SIMD)
+        case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
     }
 }
+// geometries 2..9 can run the init block themselves (states != nullptr); 0 / 1 (32x32x16) need it launched in front
+bool tower_geometry_has_init(int geometry) { return geometry >= 2; }
 
 void nn_setup_kernels() {}
 
