@@ -24,8 +24,10 @@ void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
                     const uint16_t* res, uint16_t* out, float* out_v, int G, int N);
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
-                  uint16_t* x_out, int G, const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr);
-bool tower_geometry_has_init(int geometry);   // the fused geometry can run the init block itself (states != nullptr)
+                  uint16_t* x_out, int G, const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
+                  const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr);
+bool tower_geometry_has_init(int geometry);   // the fused geometry can run the init block (states != nullptr) and the
+                                              // head convs (whead16 != nullptr: hp / hv are written, x_out is not) itself
 void launch_net16(hipStream_t st, int geometry, const void* states, const void* winit, const float* binit, const void* wt,
                   const float* bt, const void* whead, const float* bhead, uint16_t* hp, float* hv, int G);
 void nn_set_tower_dbg(unsigned long long* p);

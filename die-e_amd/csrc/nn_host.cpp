@@ -147,6 +147,7 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;
+    if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
         net->cluster_table.clear();
@@ -321,7 +322,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     auto init_block = [&] {
         launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
     };
-    bool done = false;
+    bool done = false, heads_done = false;
     if (tgeom < 0 && !W.cluster_table.empty() && W.cluster_init) {
         // small batches: init block + all 38 layers in ONE launch, 8-workgroup clusters per board group
         stamp0();
@@ -331,8 +332,9 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     if (!done && !whole && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
         // large batches: init block + all 38 layers in one launch, activations stay in LDS
         stamp0();
-        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G, states_dev, W.winit16.p, W.bconv[0].p);
-        done = true;
+        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G, states_dev, W.winit16.p, W.bconv[0].p,
+                     W.fused_heads ? W.whead16.p : nullptr, W.bconv[39].p, W.hp.p, W.hv.p);
+        done = true; heads_done = W.fused_heads;
     }
     if (!done) {
         if (!whole) init_block();
@@ -360,7 +362,7 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         HIPCHK(hipEventRecord(ev1, st));
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind});
     }
-    if (!whole) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
+    if (!whole && !heads_done) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
     if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());

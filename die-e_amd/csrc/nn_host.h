@@ -36,6 +36,7 @@ struct NetWeights {
     struct ClusterRule { int max_games, boards_per_group; };
     std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}, {256, 8}};
     DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
+    bool fused_heads = true;        // the fused tower runs the head convs itself (its output tile never leaves the CU)
     bool cluster_init = true;       // the cluster tower runs the init block itself (every workgroup, for its cluster's boards)
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias

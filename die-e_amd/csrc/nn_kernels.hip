@@ -951,7 +951,11 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
                                                     unsigned long long* dbg /* clock stamps, diagnostic builds only */,
                                                     const BgState* __restrict__ states,   // non-null: the init block runs in here
                                                     const u32x4* __restrict__ winit,      // [16][9][64] x 16 B (pack_init16)
-                                                    const float* __restrict__ binit) {
+                                                    const float* __restrict__ binit,
+                                                    const u32x4* __restrict__ whead,      // non-null: the head convs run in here
+                                                    const float* __restrict__ bhead,      // [64] (policy 0..31, value 32..34)
+                                                    uint16_t* __restrict__ hp,            // [G][768] bf16, k' = p*32 + c
+                                                    float* __restrict__ hv) {             // [G][72]  f32,  k' = p*3 + c
     constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, RS = 528, NT = 64 * NW, NFR = 16 / NW;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr bool SP = GT == 4 && DIEE_TOWER_BORDER != 0;       // border-aware row order (see border_skip)
@@ -1069,6 +1073,74 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
     if (DIEE_TOWER_ABLATE == 3 && dbg && tid == 0) {      // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
         dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
         dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    if (whead) {
+        // ---- head convs in here (nnet.rs:76-78, 88-90): policy 32 + value 3 channels = three 16-column fragments, each
+        // over the whole K; with 8 waves the fragments of a column go to two waves (every other row fragment each).
+        // The tower output never leaves the CU: no x_out store, no head-conv launch. ----
+        constexpr int HW = NW >= 6 ? 2 : 1;
+        if (wave < 3 * HW) {
+            auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
+            const int nt = wave % 3, mh = wave / 3;
+            const u32x4* wh = whead + (size_t)nt * 72 * 64 + lane;
+            constexpr int MFH = (MF + HW - 1) / HW;
+            f32x4 acc[MFH];
+#pragma unroll
+            for (int j = 0; j < MFH; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            u32x4 ring[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) ring[i] = wh[(size_t)i * 64];
+            // fragment of slot j: f = mh + HW * j (border_skip needs a constant f, so both parities are spelled out)
+            auto skipj = [&](int t, int j) -> bool {
+                if (HW == 1) return border_skip(SP, t, j);
+                return mh == 0 ? (2 * j >= MF || border_skip(SP, t, 2 * j)) : (2 * j + 1 >= MF || border_skip(SP, t, 2 * j + 1));
+            };
+            auto addrj = [&](int t, int j) -> int {
+                if (HW == 1) return baddr(t, j);
+                return mh == 0 ? baddr(t, 2 * j < MF ? 2 * j : 0) : baddr(t, 2 * j + 1 < MF ? 2 * j + 1 : 0);
+            };
+            bf16x8 ah[2][MFH];
+#pragma unroll
+            for (int j = 0; j < MFH; ++j) ah[0][j] = *(const bf16x8*)(tx + addrj(0, j));
+            for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                for (int u = 0; u < 18; ++u) {
+                    const int t = u % 9, sp = it * 18 + u + 18, cur = u & 1, nxt = cur ^ 1, un = u + 1;
+                    const int csn = it * 2 + un / 9;                  // 8 on the very last step: reads padding, unused
+#pragma unroll
+                    for (int j = 0; j < MFH; ++j) ah[nxt][j] = *(const bf16x8*)(tx + addrj(un % 9, j) + csn * 64);
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, ring[u]);
+                    ring[u] = wh[(size_t)(sp < 72 ? sp : 71) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < MFH; ++j)
+                        if (!skipj(t, j)) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, ah[cur][j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int n0 = nt * 16 + (lane >> 4) * 4;
+            const float4 bv = *(const float4*)(bhead + n0);
+#pragma unroll
+            for (int j = 0; j < MFH; ++j) {
+                const int f = mh + HW * j;
+                if (f >= MF) continue;
+                const int r = tower_row<SP>(f, lane & 15), gr = row0 + r;
+                if ((ROWS % 16 != 0 && r >= ROWS) || gr >= M) continue;
+                float v0 = acc[j][0] + bv.x, v1 = acc[j][1] + bv.y, v2 = acc[j][2] + bv.z, v3 = acc[j][3] + bv.w;
+                v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
+                const int g = gr / 24, p = gr % 24;
+                if (n0 < 32) {
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                    o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+                    *(uint2*)(hp + (size_t)g * 768 + p * 32 + n0) = o;
+                } else if (n0 == 32) {
+                    float* ov = hv + (size_t)g * 72 + p * 3;
+                    ov[0] = v0; ov[1] = v1; ov[2] = v2;
+                }
+            }
+        }
+        return;
     }
     for (int i = tid; i < ROWS * 32; i += NT) {
         const int r = i >> 5, ch = i & 31;
@@ -1391,7 +1463,8 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
 
 template <int GT, int NW, int PF>
 static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G,
-                           const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr) {
+                           const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
+                           const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr) {
     static bool attr_set = false;
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
@@ -1400,7 +1473,8 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
         attr_set = true;
     }
     hipLaunchKernelGGL((k_tower16<GT, NW, PF>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
-                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit);
+                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit,
+                       (const u32x4*)whead16, bhead, hp, hv);
 }
 template <int GT, int NW, int PF>
 static void net16_launch(hipStream_t st, const Net16Params& P) {
@@ -1427,18 +1501,19 @@ void launch_net16(hipStream_t st, int geometry, const void* states, const void* 
 // geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9: 16x16x32 MFMA (wt16 = 16-column fragments):
 // 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 3, 7, 8)
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
-                  uint16_t* x_out, int G, const void* states, const void* winit16, const float* binit) {
+                  uint16_t* x_out, int G, const void* states, const void* winit16, const float* binit,
+                  const void* whead16, const float* bhead, uint16_t* hp, float* hv) {
     switch (geometry) {
         case 0: tower_launch<4, 2, 9>(st, x_in, wt, bias, x_out, G); break;
         case 1: tower_launch<2, 1, 18>(st, x_in, wt, bias, x_out, G); break;
-        case 2: tower16_launch<4, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        case 5: tower16_launch<4, 4, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        case 3: tower16_launch<2, 8, 9>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        case 6: tower16_launch<4, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;     // 4 boards, 8 waves (2 per SIMD)
-        case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
-        default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit); break;
+        case 2: tower16_launch<4, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 5: tower16_launch<4, 4, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 3: tower16_launch<2, 8, 9>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 6: tower16_launch<4, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;     // 4 boards, 8 waves (2 per SIMD)
+        case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
     }
 }
 // geometries 2..9 can run the init block themselves (states != nullptr); 0 / 1 (32x32x16) need it launched in front
