@@ -39,7 +39,8 @@ extern "C" {
 typedef enum {
     DIEE_OK = 0,
     DIEE_ERR_ARG = 1,          /* bad argument                                            */
-    DIEE_ERR_HIP = 2,          /* HIP runtime error / no device                           */
+    DIEE_ERR_HIP = 2,          /* HIP runtime error / no device / a starved in-launch hand-over (two PROCESSES
+                                  sharing one GPU: set DIEE_TOWER_CL=none)          */
     DIEE_ERR_NO_WEIGHTS = 3,   /* diee_load_weights has not been called                   */
     DIEE_ERR_CAPACITY = 4,     /* tree arena / sequence buffer overflow (never silent)    */
     DIEE_ERR_UNSUPPORTED = 5
