@@ -74,22 +74,21 @@ def main():
     ddist = importlib.import_module("die-e_amd.dist")
     rank, local_rank, world = ddist.rank_world()
     dist = None
+    dev = local_rank
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
+        ndev = max(torch.cuda.device_count(), 1)
+        dev = local_rank % ndev
+        if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+            # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
+            # which two processes on one GPU cannot promise each other
+            os.environ["DIEE_TOWER_CL"] = "none"
+        torch.cuda.set_device(dev)                 # torch's HIP runtime initialises before libdiee.so's
         dist.init_process_group("nccl")            # "nccl" is RCCL on ROCm
 
     import diee_amd
-    dev = local_rank
-    if dist is not None:
-        import torch
-        if torch.cuda.device_count() <= local_rank:   # a launcher that narrows HIP_VISIBLE_DEVICES to one GPU per rank
-            dev = 0
-            if torch.cuda.device_count() * 1 < world and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
-                # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
-                # which two processes on one GPU cannot promise each other
-                os.environ["DIEE_TOWER_CL"] = "none"
     eng = diee_amd.Engine(dev)                     # raises without a GPU: there is no CPU path
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)

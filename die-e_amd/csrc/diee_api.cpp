@@ -25,6 +25,14 @@ using namespace diee;
         snprintf((ctx)->err, sizeof((ctx)->err), "host allocation failed"); \
         return DIEE_ERR_HIP;                                                \
     }                                                                       \
+    catch (const std::exception& e) { /* nothing may cross the C boundary */ \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s", e.what());           \
+        return DIEE_ERR_HIP;                                                \
+    }                                                                       \
+    catch (...) {                                                           \
+        snprintf((ctx)->err, sizeof((ctx)->err), "unknown exception");      \
+        return DIEE_ERR_HIP;                                                \
+    }                                                                       \
     return DIEE_OK;
 
 struct diee_ctx : public Engine {

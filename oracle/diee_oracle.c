@@ -659,65 +659,113 @@ static void expand_node(const or_game* g, or_store* st, int idx, const float* po
     free(plays); free(codes);
 }
 
-/* alpha_mcts_parallel, alpha_mcts.rs:91-202 */
+/* alpha_mcts_parallel, alpha_mcts.rs:91-202, as a resumable machine: or_mcts_next() advances to the next network
+ * evaluation (OR_MCTS_EVAL: evaluate run->batch, then or_mcts_feed()), reports an iteration the reference skips
+ * with `continue` (OR_MCTS_IDLE: nothing to evaluate, call next again) or the end (OR_MCTS_DONE).  The one-shot
+ * or_alpha_mcts_parallel below drives it with its own evaluator; or_self_play_multi drives K of them in lockstep
+ * with ONE merged evaluator call per phase (what the engine's pipelined self-play does on the GPU). */
+struct or_mcts_run {
+    const or_game* g; or_store* st; int n; or_mcts_cfg cfg;
+    uint64_t seed; uint32_t step; const uint32_t* game_ids; const uint32_t* rounds; int ref_quirks; or_stats* stats;
+    or_state* batch;          /* [n] states of the pending evaluation (stale rows keep their content)   */
+    int* sel;                 /* :142 vec![0; n] */
+    uint8_t* fresh;
+    float* noise;
+    int phase;                /* 0 = roots pending, 1 + it = iteration it pending */
+    uint32_t it;
+};
+
+or_mcts_run* or_mcts_begin(const or_game* g, or_store* st, const or_state* states, int n, const or_mcts_cfg* cfg,
+                           uint64_t seed, uint32_t step, const uint32_t* game_ids, const uint32_t* rounds,
+                           int ref_quirks, or_stats* stats) {
+    assert(st->n == 0);                                                    /* :94 */
+    or_mcts_run* r = calloc(1, sizeof *r);
+    r->g = g; r->st = st; r->n = n; r->cfg = *cfg; r->seed = seed; r->step = step;
+    r->game_ids = game_ids; r->rounds = rounds; r->ref_quirks = ref_quirks; r->stats = stats;
+    r->batch = malloc(sizeof(or_state) * (size_t)(n > 0 ? n : 1));
+    memcpy(r->batch, states, sizeof(or_state) * (size_t)n);
+    r->sel = calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    r->fresh = malloc((size_t)(n > 0 ? n : 1));
+    r->noise = malloc(sizeof(float) * (size_t)g->n_actions);
+    r->phase = 0; r->it = 0;
+    return r;
+}
+const or_state* or_mcts_batch(const or_mcts_run* r) { return r->batch; }
+int or_mcts_rows(const or_mcts_run* r) { return r->n; }
+void or_mcts_end(or_mcts_run* r) { free(r->batch); free(r->sel); free(r->fresh); free(r->noise); free(r); }
+
+int or_mcts_next(or_mcts_run* r) {
+    if (r->phase == 0) return OR_MCTS_EVAL;                                /* :97-104 forward_policy of the roots */
+    if (r->it >= r->cfg.iterations) return OR_MCTS_DONE;                   /* :149 */
+    const or_game* g = r->g; or_store* st = r->st; or_stats* stats = r->stats;
+    int node_selected = 0;
+    for (int gi = 0; gi < r->n; ++gi) {                                    /* :153-168 */
+        int depth = 0, winner = 0;
+        int idx = or_select_leaf(st, gi, r->cfg.c, &depth);
+        if (stats) { stats->selections++; stats->depth_sum += (uint64_t)depth; }
+        r->fresh[gi] = 0;
+        if (g->check_winner(&st->nodes[idx].state, &winner)) {
+            int root_player = g->get_player(&st->nodes[gi].state);
+            float v = winner == root_player ? 1.0f : (winner == -root_player ? -1.0f : 0.0f);
+            or_backpropagate(st, idx, v);
+            if (stats) stats->terminal_hits++;
+        } else {
+            node_selected = 1; r->sel[gi] = idx; r->fresh[gi] = 1;
+        }
+    }
+    if (!node_selected) { r->it++; return OR_MCTS_IDLE; }                  /* :170-172 */
+    for (int gi = 0; gi < r->n; ++gi) r->batch[gi] = st->nodes[r->sel[gi]].state;   /* :175-183 (stale slots too) */
+    return OR_MCTS_EVAL;                                                   /* :186 */
+}
+
+void or_mcts_feed(or_mcts_run* r, float* policy /* [n][A], modified in place for the roots */, const float* value) {
+    const or_game* g = r->g; or_store* st = r->st; or_stats* stats = r->stats;
+    const int A = g->n_actions, n = r->n;
+    if (stats) stats->nn_evals += (uint64_t)n;
+    if (r->phase == 0) {
+        /* apply_dirichlet, noise.rs:27-34: ONE sample shared by all rows, before masking */
+        or_dirichlet(r->seed, r->step, r->cfg.dir_alpha, A, r->noise);
+        const float eps = r->cfg.dir_eps, om = 1.0f - eps;
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < A; ++a) {
+                float x = om * policy[(size_t)i * A + a], y = eps * r->noise[a];
+                policy[(size_t)i * A + a] = x + y;
+            }
+        for (int i = 0; i < n; ++i) store_add(st, &r->batch[i], -1, -1, 0.0f);   /* :110-112 */
+        for (int i = 0; i < n; ++i) {                                      /* :119-127 */
+            st->nodes[i].visits = 1.0f;
+            expand_node(g, st, i, &policy[(size_t)i * A], r->seed, r->game_ids[i], r->rounds[i], 0, stats);
+        }
+        r->phase = 1;
+        return;
+    }
+    for (int slot = 0; slot < n; ++slot) {                                 /* :192-200 */
+        if (!r->ref_quirks && !r->fresh[slot]) continue;                   /* clean variant: no stale re-backprop */
+        int idx = r->sel[slot];
+        /* child dice are keyed by the game that owns the node: a stale slot never creates children */
+        expand_node(g, st, idx, &policy[(size_t)slot * A], r->seed, r->game_ids[slot], r->rounds[slot], r->it + 1, stats);
+        or_backpropagate(st, idx, value[slot]);
+    }
+    r->it++;
+}
+
 void or_alpha_mcts_parallel(const or_game* g, or_store* st, const or_state* states, int n,
                             const or_mcts_cfg* cfg, or_eval_fn eval, void* ectx,
                             uint64_t seed, uint32_t step, const uint32_t* game_ids,
                             const uint32_t* rounds, int ref_quirks, or_stats* stats) {
-    assert(st->n == 0);                                                    /* :94 */
     const int A = g->n_actions;
     float* policy = malloc(sizeof(float) * (size_t)n * (size_t)A);
     float* value = malloc(sizeof(float) * (size_t)n);
-    or_state* batch = malloc(sizeof(or_state) * (size_t)n);
-    float* noise = malloc(sizeof(float) * (size_t)A);
-
-    eval(ectx, states, n, policy, value);                                  /* :97-104 forward_policy */
-    if (stats) stats->nn_evals += (uint64_t)n;
-    /* apply_dirichlet, noise.rs:27-34: ONE sample shared by all rows, before masking */
-    or_dirichlet(seed, step, cfg->dir_alpha, A, noise);
-    const float eps = cfg->dir_eps, om = 1.0f - eps;
-    for (int i = 0; i < n; ++i)
-        for (int a = 0; a < A; ++a) {
-            float x = om * policy[(size_t)i * A + a], y = eps * noise[a];
-            policy[(size_t)i * A + a] = x + y;
-        }
-    for (int i = 0; i < n; ++i) store_add(st, &states[i], -1, -1, 0.0f);   /* :110-112 */
-    for (int i = 0; i < n; ++i) {                                          /* :119-127 */
-        st->nodes[i].visits = 1.0f;
-        expand_node(g, st, i, &policy[(size_t)i * A], seed, game_ids[i], rounds[i], 0, stats);
+    or_mcts_run* r = or_mcts_begin(g, st, states, n, cfg, seed, step, game_ids, rounds, ref_quirks, stats);
+    for (;;) {
+        const int what = or_mcts_next(r);
+        if (what == OR_MCTS_DONE) break;
+        if (what == OR_MCTS_IDLE) continue;
+        eval(ectx, or_mcts_batch(r), n, policy, value);
+        or_mcts_feed(r, policy, value);
     }
-
-    int* sel = calloc((size_t)n, sizeof(int));                             /* :142 vec![0; n] */
-    uint8_t* fresh = malloc((size_t)n);
-    for (uint32_t it = 0; it < cfg->iterations; ++it) {                    /* :149 */
-        int node_selected = 0;
-        for (int gi = 0; gi < n; ++gi) {                                   /* :153-168 */
-            int depth = 0, winner = 0;
-            int idx = or_select_leaf(st, gi, cfg->c, &depth);
-            if (stats) { stats->selections++; stats->depth_sum += (uint64_t)depth; }
-            fresh[gi] = 0;
-            if (g->check_winner(&st->nodes[idx].state, &winner)) {
-                int root_player = g->get_player(&st->nodes[gi].state);
-                float v = winner == root_player ? 1.0f : (winner == -root_player ? -1.0f : 0.0f);
-                or_backpropagate(st, idx, v);
-                if (stats) stats->terminal_hits++;
-            } else {
-                node_selected = 1; sel[gi] = idx; fresh[gi] = 1;
-            }
-        }
-        if (!node_selected) continue;                                      /* :170-172 */
-        for (int gi = 0; gi < n; ++gi) batch[gi] = st->nodes[sel[gi]].state;   /* :175-183 (stale slots too) */
-        eval(ectx, batch, n, policy, value);                               /* :186 */
-        if (stats) stats->nn_evals += (uint64_t)n;
-        for (int slot = 0; slot < n; ++slot) {                             /* :192-200 */
-            if (!ref_quirks && !fresh[slot]) continue;                     /* clean variant: no stale re-backprop */
-            int idx = sel[slot];
-            /* child dice are keyed by the game that owns the node: a stale slot never creates children */
-            expand_node(g, st, idx, &policy[(size_t)slot * A], seed, game_ids[slot], rounds[slot], it + 1, stats);
-            or_backpropagate(st, idx, value[slot]);
-        }
-    }
-    free(policy); free(value); free(batch); free(noise); free(sel); free(fresh);
+    or_mcts_end(r);
+    free(policy); free(value);
 }
 
 /* get_prob_tensor_parallel, utils.rs:42-58: root child visits scattered at encode(action) / row sum.
@@ -776,115 +824,227 @@ static int weighted_select(const float* w, int A, double u01) {
     return last_nz;
 }
 
+/* one self-play batch (= one call of self_play_parallel) as a steppable object: sp_roots() lists the live games'
+ * states for alpha_mcts_parallel (:131-146), sp_apply() is the per-game loop body after the search (:164-228) */
+typedef struct {
+    const or_game* g; uint32_t n_games, first_game_id; or_mcts_cfg cfg; float inv_t; uint64_t seed; int ref_quirks;
+    or_state* states; uint32_t* n_rounds; uint8_t* live; mem_list* mem; int out_cap;
+    or_fragments* out; or_stats* stats; uint32_t* plies; int8_t* winners;
+    or_state* roots; uint32_t *ids, *gids, *rnds; float *probs, *planes;
+    uint32_t n_live, m;
+} sp_batch;
+
+static void sp_init(sp_batch* b, const or_game* g, uint32_t n_games, uint32_t first_game_id, const or_mcts_cfg* cfg,
+                    float temperature, uint64_t seed, int ref_quirks, or_fragments* out, or_stats* stats,
+                    uint32_t* plies, int8_t* winners) {
+    const int A = g->n_actions, P = g->n_planes;
+    memset(b, 0, sizeof *b);
+    b->g = g; b->n_games = n_games; b->first_game_id = first_game_id; b->cfg = *cfg; b->seed = seed;
+    b->ref_quirks = ref_quirks; b->out = out; b->stats = stats; b->plies = plies; b->winners = winners;
+    b->inv_t = (float)(1.0 / (double)temperature);                        /* :165 pow_(1.0 / temperature) */
+    b->states = malloc(sizeof(or_state) * n_games);
+    b->n_rounds = calloc(n_games, sizeof(uint32_t));
+    b->live = malloc(n_games);
+    b->mem = calloc(n_games, sizeof(mem_list));
+    memset(out, 0, sizeof *out);
+    for (uint32_t i = 0; i < n_games; ++i) {                               /* :103-111 */
+        g->new_state(&b->states[i]);
+        if (!g->deterministic) {
+            uint8_t d0, d1; or_dice(seed, first_game_id + i, 0, OR_TAG_INIT_ROLL, 0, &d0, &d1);
+            g->set_roll(&b->states[i], d0, d1);
+        }
+        b->live[i] = 1;
+        if (winners) winners[i] = 0;
+        if (plies) plies[i] = 0;
+    }
+    b->n_live = n_games;
+    b->roots = malloc(sizeof(or_state) * n_games);
+    b->ids = malloc(sizeof(uint32_t) * n_games);
+    b->gids = malloc(sizeof(uint32_t) * n_games);
+    b->rnds = malloc(sizeof(uint32_t) * n_games);
+    b->probs = malloc(sizeof(float) * (size_t)n_games * (size_t)A);
+    b->planes = malloc(sizeof(float) * (size_t)P);
+}
+
+static uint32_t sp_roots(sp_batch* b) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < b->n_games; ++i) if (b->live[i]) {
+        b->roots[m] = b->states[i]; b->ids[m] = i; b->gids[m] = b->first_game_id + i; b->rnds[m] = b->n_rounds[i]; m++;
+    }
+    b->m = m;
+    return m;
+}
+
+static void sp_apply(sp_batch* b, const or_store* stp) {
+    const or_game* g = b->g; const or_mcts_cfg* cfg = &b->cfg; or_fragments* out = b->out; or_stats* stats = b->stats;
+    const int A = g->n_actions, P = g->n_planes;
+    const uint32_t m = b->m, first_game_id = b->first_game_id; const uint64_t seed = b->seed;
+    const int ref_quirks = b->ref_quirks;
+    or_state* states = b->states; uint32_t* n_rounds = b->n_rounds; uint8_t* live = b->live; mem_list* mem = b->mem;
+    float* probs = b->probs; float* planes = b->planes; const uint32_t* ids = b->ids;
+    or_get_prob_tensor_parallel(g, stp, (int)m, probs);                   /* :164 */
+    for (size_t q = 0; q < (size_t)m * (size_t)A; ++q)                    /* :165 */
+        probs[q] = probs[q] != probs[q] ? probs[q] : or_det_powf(probs[q], b->inv_t);
+    for (uint32_t pi = 0; pi < m; ++pi) {                                 /* :168-224 */
+        uint32_t gi = ids[pi];
+        or_state* s = &states[gi];
+        const float* row = probs + (size_t)pi * (size_t)A;
+        int removed = 0, flushed = 0;
+        if (n_rounds[gi] >= cfg->round_limit) {                           /* :172-180, no `continue` */
+            for (int k = 0; k < mem[gi].n; ++k)
+                frag_push(out, &b->out_cap, g, 0, mem[gi].f[k].ps, mem[gi].f[k].planes, first_game_id + gi);
+            removed = 1; flushed = 1;
+        }
+        /* :183-189: sum is NaN (nonzero) for a 0/0 row, so this is "root has no children" */
+        if (stp->nodes[pi].n_children == 0) {
+            n_rounds[gi] += 1;
+            uint8_t d0 = 0, d1 = 0;
+            if (!g->deterministic) or_dice(seed, first_game_id + gi, n_rounds[gi] - 1, OR_TAG_MOVE_ROLL, 0, &d0, &d1);
+            g->skip_turn(s, d0, d1);
+            if (removed) live[gi] = 0;
+            continue;
+        }
+        double u = or_uniform01(seed, first_game_id + gi, n_rounds[gi], OR_TAG_SAMPLE, 0);
+        int a = weighted_select(row, A, u);                               /* :192 */
+        /* :195-199 push MemoryFragment{outcome: player, ps, state} */
+        if (mem[gi].n == mem[gi].cap) {
+            mem[gi].cap = mem[gi].cap ? mem[gi].cap * 2 : 64;
+            mem[gi].f = realloc(mem[gi].f, sizeof(mem_frag) * (size_t)mem[gi].cap);
+        }
+        mem_frag* mf = &mem[gi].f[mem[gi].n++];
+        mf->player = (int8_t)g->get_player(s);
+        mf->ps = malloc(sizeof(float) * (size_t)A); memcpy(mf->ps, row, sizeof(float) * (size_t)A);
+        g->planes(s, planes);
+        mf->planes = malloc(sizeof(float) * (size_t)P); memcpy(mf->planes, planes, sizeof(float) * (size_t)P);
+        /* :202-210 decode, assert legal, apply */
+        or_play mv; g->decode(s, (uint32_t)a, &mv);
+        {
+            or_play* vm = malloc(sizeof(or_play) * OR_MAX_PLAYS);
+            int k = g->valid_moves(s, vm, OR_MAX_PLAYS), ok = 0;
+            for (int j = 0; j < k; ++j) if (memcmp(vm[j].mv, mv.mv, 4) == 0) ok = 1;
+            if (!ok && stats) stats->illegal_decodes++;
+            free(vm);
+        }
+        uint8_t d0 = 0, d1 = 0;
+        if (!g->deterministic) or_dice(seed, first_game_id + gi, n_rounds[gi], OR_TAG_MOVE_ROLL, 0, &d0, &d1);
+        g->apply_move(s, &mv, d0, d1);
+        n_rounds[gi] += 1;                                                /* :213 */
+        int winner = 0;
+        if (g->check_winner(s, &winner)) {                                /* :215-223 */
+            if (!(flushed && !ref_quirks)) {                              /* Q18: the reference flushes twice */
+                for (int k = 0; k < mem[gi].n; ++k) {
+                    int8_t pl = mem[gi].f[k].player;
+                    int8_t oc = winner == pl ? 1 : (winner == -pl ? -1 : 0);
+                    frag_push(out, &b->out_cap, g, oc, mem[gi].f[k].ps, mem[gi].f[k].planes, first_game_id + gi);
+                }
+            }
+            if (b->winners) b->winners[gi] = (int8_t)winner;
+            removed = 1;
+        }
+        if (removed) live[gi] = 0;
+    }
+    for (uint32_t i = 0; i < b->n_games; ++i) if (b->plies) b->plies[i] = n_rounds[i];
+    b->n_live = 0;
+    for (uint32_t i = 0; i < b->n_games; ++i) b->n_live += live[i];
+}
+
+static void sp_free(sp_batch* b) {
+    for (uint32_t i = 0; i < b->n_games; ++i) {
+        for (int k = 0; k < b->mem[i].n; ++k) { free(b->mem[i].f[k].ps); free(b->mem[i].f[k].planes); }
+        free(b->mem[i].f);
+    }
+    free(b->states); free(b->n_rounds); free(b->live); free(b->mem); free(b->roots); free(b->ids); free(b->gids);
+    free(b->rnds); free(b->probs); free(b->planes);
+}
+
 int or_self_play_parallel(const or_game* g, uint32_t n_games, uint32_t first_game_id,
                           const or_mcts_cfg* cfg, float temperature, uint64_t seed,
                           or_eval_fn eval, void* ectx, int ref_quirks, uint32_t max_steps,
                           or_fragments* out, or_stats* stats, uint32_t* plies, int8_t* winners) {
-    const int A = g->n_actions, P = g->n_planes;
-    or_state* states = malloc(sizeof(or_state) * n_games);
-    uint32_t* n_rounds = calloc(n_games, sizeof(uint32_t));
-    uint8_t* live = malloc(n_games);
-    mem_list* mem = calloc(n_games, sizeof(mem_list));
-    int out_cap = 0;
-    memset(out, 0, sizeof *out);
-    for (uint32_t i = 0; i < n_games; ++i) {                               /* :103-111 */
-        g->new_state(&states[i]);
-        if (!g->deterministic) {
-            uint8_t d0, d1; or_dice(seed, first_game_id + i, 0, OR_TAG_INIT_ROLL, 0, &d0, &d1);
-            g->set_roll(&states[i], d0, d1);
-        }
-        live[i] = 1;
-        if (winners) winners[i] = 0;
-        if (plies) plies[i] = 0;
-    }
-    uint32_t n_live = n_games, step = 0;
-    or_state* roots = malloc(sizeof(or_state) * n_games);
-    uint32_t* ids = malloc(sizeof(uint32_t) * n_games);
-    uint32_t* gids = malloc(sizeof(uint32_t) * n_games);
-    uint32_t* rnds = malloc(sizeof(uint32_t) * n_games);
-    float* probs = malloc(sizeof(float) * (size_t)n_games * (size_t)A);
-    float* planes = malloc(sizeof(float) * (size_t)P);
-    const float inv_t = (float)(1.0 / (double)temperature);              /* :165 pow_(1.0 / temperature) */
-    while (n_live > 0 && (max_steps == 0 || step < max_steps)) {          /* :129 */
-        uint32_t m = 0;
-        for (uint32_t i = 0; i < n_games; ++i) if (live[i]) {
-            roots[m] = states[i]; ids[m] = i; gids[m] = first_game_id + i; rnds[m] = n_rounds[i]; m++;
-        }
+    sp_batch b;
+    sp_init(&b, g, n_games, first_game_id, cfg, temperature, seed, ref_quirks, out, stats, plies, winners);
+    uint32_t step = 0;
+    while (b.n_live > 0 && (max_steps == 0 || step < max_steps)) {        /* :129 */
+        const uint32_t m = sp_roots(&b);
         or_store st; or_store_init(&st);                                  /* :137 fresh store every move-step */
-        or_alpha_mcts_parallel(g, &st, roots, (int)m, cfg, eval, ectx, seed, step, gids, rnds, ref_quirks, stats);
-        or_get_prob_tensor_parallel(g, &st, (int)m, probs);               /* :164 */
-        for (size_t q = 0; q < (size_t)m * (size_t)A; ++q)                /* :165 */
-            probs[q] = probs[q] != probs[q] ? probs[q] : or_det_powf(probs[q], inv_t);
-        for (uint32_t pi = 0; pi < m; ++pi) {                             /* :168-224 */
-            uint32_t gi = ids[pi];
-            or_state* s = &states[gi];
-            const float* row = probs + (size_t)pi * (size_t)A;
-            int removed = 0, flushed = 0;
-            if (n_rounds[gi] >= cfg->round_limit) {                       /* :172-180, no `continue` */
-                for (int k = 0; k < mem[gi].n; ++k)
-                    frag_push(out, &out_cap, g, 0, mem[gi].f[k].ps, mem[gi].f[k].planes, first_game_id + gi);
-                removed = 1; flushed = 1;
-            }
-            /* :183-189: sum is NaN (nonzero) for a 0/0 row, so this is "root has no children" */
-            if (st.nodes[pi].n_children == 0) {
-                n_rounds[gi] += 1;
-                uint8_t d0 = 0, d1 = 0;
-                if (!g->deterministic) or_dice(seed, first_game_id + gi, n_rounds[gi] - 1, OR_TAG_MOVE_ROLL, 0, &d0, &d1);
-                g->skip_turn(s, d0, d1);
-                if (removed) live[gi] = 0;
-                continue;
-            }
-            double u = or_uniform01(seed, first_game_id + gi, n_rounds[gi], OR_TAG_SAMPLE, 0);
-            int a = weighted_select(row, A, u);                           /* :192 */
-            /* :195-199 push MemoryFragment{outcome: player, ps, state} */
-            if (mem[gi].n == mem[gi].cap) {
-                mem[gi].cap = mem[gi].cap ? mem[gi].cap * 2 : 64;
-                mem[gi].f = realloc(mem[gi].f, sizeof(mem_frag) * (size_t)mem[gi].cap);
-            }
-            mem_frag* mf = &mem[gi].f[mem[gi].n++];
-            mf->player = (int8_t)g->get_player(s);
-            mf->ps = malloc(sizeof(float) * (size_t)A); memcpy(mf->ps, row, sizeof(float) * (size_t)A);
-            g->planes(s, planes);
-            mf->planes = malloc(sizeof(float) * (size_t)P); memcpy(mf->planes, planes, sizeof(float) * (size_t)P);
-            /* :202-210 decode, assert legal, apply */
-            or_play mv; g->decode(s, (uint32_t)a, &mv);
-            {
-                or_play* vm = malloc(sizeof(or_play) * OR_MAX_PLAYS);
-                int k = g->valid_moves(s, vm, OR_MAX_PLAYS), ok = 0;
-                for (int j = 0; j < k; ++j) if (memcmp(vm[j].mv, mv.mv, 4) == 0) ok = 1;
-                if (!ok && stats) stats->illegal_decodes++;
-                free(vm);
-            }
-            uint8_t d0 = 0, d1 = 0;
-            if (!g->deterministic) or_dice(seed, first_game_id + gi, n_rounds[gi], OR_TAG_MOVE_ROLL, 0, &d0, &d1);
-            g->apply_move(s, &mv, d0, d1);
-            n_rounds[gi] += 1;                                            /* :213 */
-            int winner = 0;
-            if (g->check_winner(s, &winner)) {                            /* :215-223 */
-                if (!(flushed && !ref_quirks)) {                          /* Q18: the reference flushes twice */
-                    for (int k = 0; k < mem[gi].n; ++k) {
-                        int8_t pl = mem[gi].f[k].player;
-                        int8_t oc = winner == pl ? 1 : (winner == -pl ? -1 : 0);
-                        frag_push(out, &out_cap, g, oc, mem[gi].f[k].ps, mem[gi].f[k].planes, first_game_id + gi);
-                    }
-                }
-                if (winners) winners[gi] = (int8_t)winner;
-                removed = 1;
-            }
-            if (removed) live[gi] = 0;
-        }
-        for (uint32_t i = 0; i < n_games; ++i) if (plies) plies[i] = n_rounds[i];
-        n_live = 0;
-        for (uint32_t i = 0; i < n_games; ++i) n_live += live[i];
+        or_alpha_mcts_parallel(g, &st, b.roots, (int)m, cfg, eval, ectx, seed, step, b.gids, b.rnds, ref_quirks, stats);
+        sp_apply(&b, &st);
         or_store_free(&st);
         step++;
     }
-    for (uint32_t i = 0; i < n_games; ++i) {
-        for (int k = 0; k < mem[i].n; ++k) { free(mem[i].f[k].ps); free(mem[i].f[k].planes); }
-        free(mem[i].f);
+    sp_free(&b);
+    return (int)step;
+}
+
+/* K independent self_play_parallel calls (same network, same MctsConfig; own seed, game ids and outputs -- what
+ * learn_parallel issues back to back, alpha_parallel.rs:49-62) advanced in LOCKSTEP: all batches start at move-step 0
+ * and every phase of the search (root evaluation, then each iteration) evaluates ONE merged batch: the live games of
+ * batch 0, then of batch 1, ...  A batch whose iteration is skipped (`continue`, :170-172) still occupies its rows
+ * (stale content, results ignored), a finished batch has none.  With an evaluator that is a pure function of the
+ * state, batch k's records equal or_self_play_parallel(seed k) byte for byte; with the engine's ResNet as evaluator
+ * they equal the engine's pipelined self-play, which merges its network batches the same way. */
+int or_self_play_multi(const or_game* g, uint32_t n_batches, const uint32_t* n_games, const uint32_t* first_game_ids,
+                       const uint64_t* seeds, const or_mcts_cfg* cfg, float temperature, or_eval_fn eval, void* ectx,
+                       int ref_quirks, uint32_t max_steps, or_fragments* outs /* [n_batches] */,
+                       or_stats* stats /* [n_batches] */, uint32_t* steps /* [n_batches] or NULL */) {
+    const int A = g->n_actions;
+    sp_batch* b = malloc(sizeof(sp_batch) * n_batches);
+    or_store* st = malloc(sizeof(or_store) * n_batches);
+    or_mcts_run** run = malloc(sizeof(or_mcts_run*) * n_batches);
+    int* what = malloc(sizeof(int) * n_batches);
+    size_t total = 0;
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        sp_init(&b[k], g, n_games[k], first_game_ids[k], cfg, temperature, seeds[k], ref_quirks, &outs[k], &stats[k], NULL, NULL);
+        total += n_games[k];
+        if (steps) steps[k] = 0;
     }
-    free(states); free(n_rounds); free(live); free(mem); free(roots); free(ids); free(gids); free(rnds);
-    free(probs); free(planes);
+    or_state* merged = malloc(sizeof(or_state) * (total ? total : 1));
+    float* policy = malloc(sizeof(float) * (total ? total : 1) * (size_t)A);
+    float* value = malloc(sizeof(float) * (total ? total : 1));
+    uint32_t step = 0;
+    for (;;) {
+        uint32_t alive = 0;
+        for (uint32_t k = 0; k < n_batches; ++k) alive += b[k].n_live;
+        if (!alive || (max_steps && step >= max_steps)) break;
+        for (uint32_t k = 0; k < n_batches; ++k) {
+            run[k] = NULL;
+            if (!b[k].n_live) continue;
+            const uint32_t m = sp_roots(&b[k]);
+            or_store_init(&st[k]);
+            run[k] = or_mcts_begin(g, &st[k], b[k].roots, (int)m, cfg, seeds[k], step, b[k].gids, b[k].rnds, ref_quirks, &stats[k]);
+            if (steps) steps[k] = step + 1;
+        }
+        for (;;) {                                                        /* root phase, then one phase per iteration */
+            int done = 1, any_eval = 0;
+            size_t rows = 0;
+            for (uint32_t k = 0; k < n_batches; ++k) {
+                if (!run[k]) continue;
+                what[k] = or_mcts_next(run[k]);
+                if (what[k] != OR_MCTS_DONE) done = 0;
+                if (what[k] == OR_MCTS_EVAL) any_eval = 1;
+                memcpy(merged + rows, or_mcts_batch(run[k]), sizeof(or_state) * (size_t)or_mcts_rows(run[k]));
+                rows += (size_t)or_mcts_rows(run[k]);
+            }
+            if (done) break;
+            if (!any_eval) continue;
+            eval(ectx, merged, (int)rows, policy, value);
+            rows = 0;
+            for (uint32_t k = 0; k < n_batches; ++k) {
+                if (!run[k]) continue;
+                if (what[k] == OR_MCTS_EVAL) or_mcts_feed(run[k], policy + rows * (size_t)A, value + rows);
+                rows += (size_t)or_mcts_rows(run[k]);
+            }
+        }
+        for (uint32_t k = 0; k < n_batches; ++k) {
+            if (!run[k]) continue;
+            or_mcts_end(run[k]);
+            sp_apply(&b[k], &st[k]);
+            or_store_free(&st[k]);
+        }
+        step++;
+    }
+    for (uint32_t k = 0; k < n_batches; ++k) sp_free(&b[k]);
+    free(b); free(st); free(run); free(what); free(merged); free(policy); free(value);
     return (int)step;
 }
 

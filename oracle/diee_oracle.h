@@ -160,6 +160,18 @@ void or_alpha_mcts_parallel(const or_game* g, or_store* st, const or_state* stat
                             const or_mcts_cfg* cfg, or_eval_fn eval, void* ectx,
                             uint64_t seed, uint32_t step, const uint32_t* game_ids,
                             const uint32_t* rounds, int ref_quirks, or_stats* stats);
+/* the same search as a resumable machine (one network evaluation per step), so that several batches can share
+ * one evaluator call: begin -> { next: EVAL -> evaluate or_mcts_batch() -> feed | IDLE | DONE } -> end */
+typedef struct or_mcts_run or_mcts_run;
+enum { OR_MCTS_DONE = 0, OR_MCTS_EVAL = 1, OR_MCTS_IDLE = 2 };
+or_mcts_run* or_mcts_begin(const or_game* g, or_store* st, const or_state* states, int n, const or_mcts_cfg* cfg,
+                           uint64_t seed, uint32_t step, const uint32_t* game_ids, const uint32_t* rounds,
+                           int ref_quirks, or_stats* stats);
+int  or_mcts_next(or_mcts_run* r);
+const or_state* or_mcts_batch(const or_mcts_run* r);
+int  or_mcts_rows(const or_mcts_run* r);
+void or_mcts_feed(or_mcts_run* r, float* policy, const float* value);
+void or_mcts_end(or_mcts_run* r);
 /* get_prob_tensor_parallel, utils.rs:42-58: probs[n][A] */
 void or_get_prob_tensor_parallel(const or_game* g, const or_store* st, int n, float* probs);
 
@@ -177,6 +189,10 @@ int  or_self_play_parallel(const or_game* g, uint32_t n_games, uint32_t first_ga
                            or_eval_fn eval, void* ectx, int ref_quirks, uint32_t max_steps,
                            or_fragments* out, or_stats* stats,
                            uint32_t* plies /* [n_games] or NULL */, int8_t* winners /* or NULL */);
+/* K self_play_parallel calls in lockstep, one merged evaluator call per search phase (see diee_oracle.c) */
+int  or_self_play_multi(const or_game* g, uint32_t n_batches, const uint32_t* n_games, const uint32_t* first_game_ids,
+                        const uint64_t* seeds, const or_mcts_cfg* cfg, float temperature, or_eval_fn eval, void* ectx,
+                        int ref_quirks, uint32_t max_steps, or_fragments* outs, or_stats* stats, uint32_t* steps);
 void or_free_fragments(or_fragments* f);
 
 /* a cheap deterministic evaluator for CPU-only tests (NOT a network) */

@@ -109,6 +109,8 @@ def lib():
         L.or_get_prob_tensor_parallel.argtypes = [vp, vp, i, vp]
         L.or_self_play_parallel.argtypes = [vp, u32, u32, vp, C.c_float, u64, EVAL_FN, vp, i, u32, vp, vp, vp, vp]
         L.or_self_play_parallel.restype = i
+        L.or_self_play_multi.argtypes = [vp, u32, vp, vp, vp, vp, C.c_float, EVAL_FN, vp, i, u32, vp, vp, vp]
+        L.or_self_play_multi.restype = i
         L.or_free_fragments.argtypes = [vp]
         L.or_random_walk_states.argtypes = [u64, u32, u32, vp, i]; L.or_random_walk_states.restype = i
         L.or_bg_valid_moves_batch.argtypes = [vp, i, vp, i, vp]
@@ -353,6 +355,40 @@ def self_play_parallel(game_id, n_games, cfg, temperature, seed, eval_fn, ectx, 
     }
     L.or_free_fragments(C.byref(fr))
     return out
+
+
+def _fragments_dict(fr, game_id):
+    A = 9 if game_id == 0 else BG_ACTIONS
+    P = 27 if game_id == 0 else BG_PLANES
+    n = fr.n
+    return {
+        "outcome": np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8),
+        "ps": np.ctypeslib.as_array(fr.ps, shape=(n, A)).copy() if n else np.zeros((0, A), np.float32),
+        "state": np.ctypeslib.as_array(fr.state, shape=(n, P)).copy() if n else np.zeros((0, P), np.float32),
+        "game": np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32),
+    }
+
+
+def self_play_multi(game_id, batches, cfg, temperature, eval_fn, ectx, ref_quirks=1, max_steps=0):
+    """K self_play_parallel calls in lockstep with ONE merged evaluator call per search phase.
+    batches = [(n_games, first_game_id, seed), ...] -> list of per-batch dicts (like self_play_parallel's)"""
+    L = lib()
+    g = game(game_id)
+    K = len(batches)
+    ng = np.array([b[0] for b in batches], dtype=np.uint32)
+    fi = np.array([b[1] for b in batches], dtype=np.uint32)
+    sd = np.array([b[2] for b in batches], dtype=np.uint64)
+    frs = (Fragments * K)(); sts = (Stats * K)()
+    steps = np.zeros(K, dtype=np.uint32)
+    total = L.or_self_play_multi(g, K, ng.ctypes.data, fi.ctypes.data, sd.ctypes.data, C.byref(cfg), temperature,
+                                 eval_fn, ectx, ref_quirks, max_steps, C.byref(frs), C.byref(sts), steps.ctypes.data)
+    out = []
+    for k in range(K):
+        d = _fragments_dict(frs[k], game_id)
+        d["stats"] = sts[k].as_dict(); d["steps"] = int(steps[k])
+        out.append(d)
+        L.or_free_fragments(C.byref(frs[k]))
+    return out, total
 
 
 # --------------------------------------------------------------------------- batch helpers

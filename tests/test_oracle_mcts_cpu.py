@@ -183,3 +183,47 @@ def test_sharding_reproduces_the_unsharded_batch(oracle):
         part = a if g < 3 else b
         for key in ("ps", "state", "outcome"):
             assert part[key][part["game"] == g].tobytes() == full[key][full["game"] == g].tobytes(), (g, key)
+
+
+def test_self_play_multi_equals_sequential_calls(oracle):
+    """K batches in lockstep with one merged evaluator call per search phase (what the engine's pipelined self-play
+    does): with an evaluator that is a pure function of the state, every batch's records, statistics and length equal
+    its own self_play_parallel call byte for byte -- quirks on (Q14 couples the games of ONE batch only) and off"""
+    cfg = oracle.MctsCfg(iterations=10, c=2.0, round_limit=50, dir_alpha=0.3, dir_eps=0.25)
+    batches = [(5, 0, 11), (3, 40, 12), (1, 7, 13), (6, 100, 11)]
+    for quirks in (1, 0):
+        multi, total = oracle.self_play_multi(1, batches, cfg, 1.25, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=quirks)
+        longest = 0
+        for (n, first, seed), m in zip(batches, multi):
+            ref = oracle.self_play_parallel(1, n, cfg, 1.25, seed, oracle.hash_eval_fn(), oracle.game(1),
+                                            ref_quirks=quirks, first_game_id=first)
+            assert m["steps"] == ref["steps"]
+            longest = max(longest, ref["steps"])
+            assert (m["game"] == ref["game"]).all() and (m["outcome"] == ref["outcome"]).all()
+            assert m["ps"].tobytes() == ref["ps"].tobytes() and m["state"].tobytes() == ref["state"].tobytes()
+            assert m["stats"] == ref["stats"]
+        assert total == longest
+
+
+def test_self_play_multi_merges_rows_in_batch_order(oracle):
+    """the merged evaluator call holds the live games of batch 0, then batch 1, ...: row counts per phase shrink as
+    games retire and never exceed the total number of games"""
+    import numpy as np
+    cfg = oracle.MctsCfg(iterations=4, c=2.0, round_limit=30, dir_alpha=0.3, dir_eps=0.25)
+    sizes = []
+    base = oracle.hash_eval_fn()
+
+    def fn(states_u8):
+        sizes.append(len(states_u8))
+        n = len(states_u8)
+        pol = np.zeros((n, 1352), dtype=np.float32); val = np.zeros(n, dtype=np.float32)
+        st = np.ascontiguousarray(states_u8)
+        base(oracle.game(1), st.ctypes.data, n, pol.ctypes.data_as(oracle.C.POINTER(oracle.C.c_float)),
+             val.ctypes.data_as(oracle.C.POINTER(oracle.C.c_float)))
+        return pol, val
+    ev = oracle.make_eval(fn, 1352)
+    multi, total = oracle.self_play_multi(1, [(4, 0, 5), (4, 10, 6)], cfg, 1.25, ev, None, ref_quirks=1)
+    assert sizes[0] == 8 and max(sizes) == 8 and sizes[-1] >= 1
+    assert all(a >= b for a, b in zip(sizes, sizes[1:]))             # constant within a move-step, shrinking across them
+    ref = oracle.self_play_parallel(1, 4, cfg, 1.25, 6, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=1, first_game_id=10)
+    assert multi[1]["ps"].tobytes() == ref["ps"].tobytes()
