@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
+    ap.add_argument("--pipeline", type=int, default=4, help="also time K batches played side by side through diee_self_play_multi "
+                    "(self_play_iterations of the learn loop; 0 = skip); reported as value_pipelined, never as value")
     args = ap.parse_args()
 
     import importlib
@@ -118,6 +120,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # ---- second figure: the same batches, K at a time, sharing every network launch (diee_self_play_multi) ----
+    pipe = None
+    if args.pipeline > 1:
+        K = args.pipeline
+        batches = [(args.games, first_id, args.seed + 0x9E37 * i) for i in range(K)]
+        eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, max_steps=1, fetch=False)      # sizes the arenas
+        barrier()
+        tp0 = time.perf_counter()
+        sts = [o["stats"] for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=False, max_steps=args.max_steps)]
+        barrier()
+        dtp = time.perf_counter() - tp0
+        pipe = {k: sum(st[k] for st in sts) for k in ("games", "expansions", "nn_evals", "plies", "fragments")}
+        pipe["move_steps"] = max(st["move_steps"] for st in sts)
+        pipe["tower_seconds"], pipe["tower_launches"], pipe["tower_flops"] = (sts[0][k] for k in ("tower_seconds", "tower_launches", "tower_flops"))
+
     keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
@@ -125,6 +142,10 @@ def main():
     if dist is not None:
         dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
         tot.update(red)
+        if pipe is not None:
+            pkeys = ["games", "expansions", "nn_evals", "plies", "fragments", "tower_seconds", "tower_launches", "tower_flops"]
+            dtp, red = ddist.reduce_stats(dist, dtp, pipe, pkeys, "cuda")
+            pipe.update(red)
 
     if rank == 0:
         games = tot["games"]
@@ -146,7 +167,9 @@ def main():
                 return None
             a = flops / sec / 1e12
             return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": a / PEAK_BF16_TFLOPS, "traffic": traffic, "launches_sampled": launches / world,
+                    "frac": a / PEAK_BF16_TFLOPS, "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/ (separate rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
+                    "launches_sampled": launches / world,
                     "avg_launch_us": sec / max(launches, 1) * 1e6,
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
                     "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"])}
@@ -179,6 +202,19 @@ def main():
                       "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"]},
             "roofline": dominant, "roofline_other": other,
         }
+        if pipe is not None:
+            # NOT the headline: `value` above stays one self_play_parallel call per step, as the reference issues them
+            out["value_pipelined"] = pipe["games"] / dtp
+            out["pipelined"] = {
+                "what": f"{args.pipeline} self_play_parallel batches of {args.games} games per GPU played side by side in one "
+                        "diee_self_play_multi call (the learn loop's self_play_iterations, alpha_parallel.rs:49-62): all "
+                        "batches share every network launch, each keeps its own seed / Dirichlet stream / Q14 bookkeeping",
+                "batches": args.pipeline, "seconds": dtp, "games": pipe["games"], "move_steps": pipe["move_steps"],
+                "node_expansions_per_s": pipe["expansions"] / dtp, "nn_evals_per_s": pipe["nn_evals"] / dtp,
+                "mfma_fraction_end_to_end": pipe["nn_evals"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
+                "fused_tower_tflops": (pipe["tower_flops"] / pipe["tower_seconds"] / 1e12) if pipe["tower_seconds"] else None,
+                "fused_tower_avg_launch_us": (pipe["tower_seconds"] / max(pipe["tower_launches"], 1) * 1e6) if pipe["tower_seconds"] else None,
+            }
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(8, args.iterations, 2, args.seed, exp_per_game)

@@ -28,6 +28,7 @@ BG_PLANES = 144
 NO_MOVE = -2
 GAME_TTT, GAME_BACKGAMMON = 0, 1
 FLAG_REF_QUIRKS = 1
+FLAG_INVARIANT_NN = 2
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_WEIGHTS, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
 
@@ -39,6 +40,7 @@ assert BG_STATE.itemsize == 32
 EXPORTS = [
     "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
     "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
+    "diee_self_play_multi", "diee_set_invariant_nn",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
     "diee_bg_planes", "diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench",
 ]
@@ -79,6 +81,11 @@ class Fragments(C.Structure):
                 ("state", C.POINTER(C.c_float)), ("game", C.POINTER(C.c_uint32))]
 
 
+class Batch(C.Structure):
+    """diee_batch: one self_play_parallel call of a pipelined diee_self_play_multi"""
+    _fields_ = [("n_games", C.c_uint32), ("first_game_id", C.c_uint32), ("seed", C.c_uint64)]
+
+
 _lib = None
 _TORCH_LOADED_FIRST = False     # PyTorch bundles its own ROCm runtime libraries.  Whichever side is loaded first
                                 # provides them to the whole process (same sonames): if torch came first both torch.cuda
@@ -111,6 +118,8 @@ def load_library(path=None):
     L.diee_mcts_batch.argtypes = [vp, vp, u32, vp, u64, u32, vp, vp, u32, vp, vp, vp, vp]
     L.diee_mcts_batch.restype = C.c_int
     L.diee_self_play.argtypes = [vp, u32, u32, vp, f32, u64, u32, u32, vp, vp]; L.diee_self_play.restype = C.c_int
+    L.diee_self_play_multi.argtypes = [vp, vp, u32, vp, f32, u32, u32, vp, vp]; L.diee_self_play_multi.restype = C.c_int
+    L.diee_set_invariant_nn.argtypes = [vp, C.c_int]; L.diee_set_invariant_nn.restype = C.c_int
     L.diee_free_fragments.argtypes = [vp]; L.diee_free_fragments.restype = None
     L.diee_bg_legal_moves.argtypes = [vp, vp, u32, vp, u32, vp]; L.diee_bg_legal_moves.restype = C.c_int
     L.diee_bg_encode.argtypes = [vp, vp, vp, u32, vp]; L.diee_bg_encode.restype = C.c_int
@@ -253,6 +262,10 @@ class Engine:
         return us.value, k.value
 
     # ---- search ------------------------------------------------------------------------------
+    def set_invariant_nn(self, on=True):
+        """batch-size independent network arithmetic (DIEE_FLAG_INVARIANT_NN) for every later call"""
+        self._chk(self._L.diee_set_invariant_nn(self._h, 1 if on else 0))
+
     def alpha_mcts_parallel(self, states, cfg, seed=0, step=0, game_ids=None, rounds=None, ref_quirks=True):
         """alpha_mcts_parallel + get_prob_tensor_parallel -> dict(probs [n,1352], n_children, root_visits, stats)"""
         s = _states(states); n = len(s)
@@ -268,21 +281,42 @@ class Engine:
                                           probs.ctypes.data, nch.ctypes.data, rv.ctypes.data, C.byref(st)))
         return {"probs": probs, "n_children": nch, "root_visits": rv, "stats": st.as_dict()}
 
+    def _take_fragments(self, fr, out):
+        n = fr.n
+        out["outcome"] = np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8)
+        out["ps"] = (np.ctypeslib.as_array(fr.ps, shape=(n, BG_ACTIONS)).copy() if n
+                     else np.zeros((0, BG_ACTIONS), np.float32))
+        out["state"] = (np.ctypeslib.as_array(fr.state, shape=(n, BG_PLANES)).copy() if n
+                        else np.zeros((0, BG_PLANES), np.float32))
+        out["game"] = np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        self._L.diee_free_fragments(C.byref(fr))
+
     def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0xD1EE0001, ref_quirks=True,
-                           first_game_id=0, max_steps=0, fetch=True):
+                           first_game_id=0, max_steps=0, fetch=True, invariant_nn=False):
         """AlphaZero::self_play_parallel -> dict(outcome, ps, state, game, stats)"""
         fr = Fragments(); st = Stats()
+        flags = (FLAG_REF_QUIRKS if ref_quirks else 0) | (FLAG_INVARIANT_NN if invariant_nn else 0)
         self._chk(self._L.diee_self_play(self._h, n_games, first_game_id, C.byref(cfg), temperature, seed,
-                                         FLAG_REF_QUIRKS if ref_quirks else 0, max_steps,
-                                         C.byref(fr) if fetch else None, C.byref(st)))
+                                         flags, max_steps, C.byref(fr) if fetch else None, C.byref(st)))
         out = {"stats": st.as_dict()}
         if fetch:
-            n = fr.n
-            out["outcome"] = np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8)
-            out["ps"] = (np.ctypeslib.as_array(fr.ps, shape=(n, BG_ACTIONS)).copy() if n
-                         else np.zeros((0, BG_ACTIONS), np.float32))
-            out["state"] = (np.ctypeslib.as_array(fr.state, shape=(n, BG_PLANES)).copy() if n
-                            else np.zeros((0, BG_PLANES), np.float32))
-            out["game"] = np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
-            self._L.diee_free_fragments(C.byref(fr))
+            self._take_fragments(fr, out)
         return out
+
+    def self_play_multi(self, batches, cfg, temperature=1.25, ref_quirks=True, max_steps=0, fetch=True,
+                        invariant_nn=False):
+        """K self_play_parallel calls played side by side (diee_self_play_multi): batches = [(n_games,
+        first_game_id, seed), ...] -> list of per-batch dicts like self_play_parallel's"""
+        K = len(batches)
+        bt = (Batch * K)(*[Batch(int(n), int(f), int(s)) for n, f, s in batches])
+        frs = (Fragments * K)(); sts = (Stats * K)()
+        flags = (FLAG_REF_QUIRKS if ref_quirks else 0) | (FLAG_INVARIANT_NN if invariant_nn else 0)
+        self._chk(self._L.diee_self_play_multi(self._h, C.byref(bt), K, C.byref(cfg), temperature, flags, max_steps,
+                                               C.byref(frs) if fetch else None, C.byref(sts)))
+        outs = []
+        for k in range(K):
+            out = {"stats": sts[k].as_dict()}
+            if fetch:
+                self._take_fragments(frs[k], out)
+            outs.append(out)
+        return outs

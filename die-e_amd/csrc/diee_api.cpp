@@ -138,6 +138,13 @@ diee_status diee_load_weights(diee_ctx* c, const float* blob, size_t n) {
     API_END(c)
 }
 
+diee_status diee_set_invariant_nn(diee_ctx* c, int on) {
+    API_BEGIN(c)
+    if (!c->net) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    c->net->invariant = on != 0;
+    API_END(c)
+}
+
 diee_status diee_nn_forward(diee_ctx* c, const diee_bg_state* states, uint32_t n, float* policy, float* value) {
     API_BEGIN(c)
     if (!states || !policy || !value) throw EngineError(DIEE_ERR_ARG, "null pointer");
@@ -161,6 +168,15 @@ diee_status diee_self_play(diee_ctx* c, uint32_t n_games, uint32_t first_game_id
     API_BEGIN(c)
     if (!cfg || n_games == 0) throw EngineError(DIEE_ERR_ARG, "bad arguments");
     c->self_play(n_games, first_game_id, cfg, temperature, seed, flags, max_steps, out, stats);
+    API_END(c)
+}
+
+diee_status diee_self_play_multi(diee_ctx* c, const diee_batch* batches, uint32_t n_batches, const diee_mcts_cfg* cfg,
+                                 float temperature, uint32_t flags, uint32_t max_steps, diee_fragments* outs,
+                                 diee_stats* stats) {
+    API_BEGIN(c)
+    if (!cfg || !batches) throw EngineError(DIEE_ERR_ARG, "bad arguments");
+    c->self_play_multi(batches, n_batches, cfg, temperature, flags, max_steps, outs, stats);
     API_END(c)
 }
 

@@ -70,6 +70,8 @@ public:
                     uint32_t* n_children, float* root_visits, diee_stats* stats);
     void self_play(uint32_t n_games, uint32_t first_game_id, const diee_mcts_cfg* cfg, float temperature,
                    uint64_t seed, uint32_t flags, uint32_t max_steps, diee_fragments* out, diee_stats* stats);
+    void self_play_multi(const diee_batch* batches, uint32_t n_batches, const diee_mcts_cfg* cfg, float temperature,
+                         uint32_t flags, uint32_t max_steps, diee_fragments* outs, diee_stats* stats);
 
     int device;
     hipStream_t stream = nullptr;

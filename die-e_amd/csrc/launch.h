@@ -35,7 +35,7 @@ void nn_set_tower_dbg(unsigned long long* p);
 // `err` gets bit 2 set if a cluster wait timed out.  false = not launched (grid would not be co-resident).
 constexpr int kClusterMaxGroups = 64;
 // `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
-bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
+bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
@@ -43,15 +43,15 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 
 // mcts_kernels.hip
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
-void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks);
-void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P,
+void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks);
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c);   // next_it: iteration to select for afterwards, kNoNextIteration = none
-void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n);
+void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits);
-void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed);
-void launch_gather_roots(hipStream_t st, const Games& G, const Slots& S, uint32_t n_live, uint32_t first_id);
-void launch_play_move(hipStream_t st, const Tree& T, const Games& G, uint32_t n_live, uint32_t step, const PlayParams& P);
-void launch_compact_live(hipStream_t st, const Games& G, uint32_t n_live, uint32_t* n_live_out);
+void launch_init_games(hipStream_t st, const Games& Gm, const Segs& G, uint32_t n);
+void launch_gather_roots(hipStream_t st, const Games& Gm, const Slots& S, const Segs& G, uint32_t n_live);
+void launch_play_move(hipStream_t st, const Tree& T, const Games& Gm, const Segs& G, uint32_t n_live, uint32_t step, const PlayParams& P);
+void launch_compact_live(hipStream_t st, const Games& Gm, uint32_t n_live, uint32_t n_segs, uint32_t* n_live_out);
 void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes);
 constexpr uint32_t kRootIteration = 0xFFFFFFFFu;
 constexpr uint32_t kNoNextIteration = 0xFFFFFFFEu;

@@ -69,9 +69,10 @@ __device__ __forceinline__ Best better(Best a, Best b) {      // later index win
 
 // alpha_select_leaf_node / select_alpha (alpha_mcts.rs:14-33) with alpha_ucb (node.rs:98-112):
 //   q + (c * (sqrt(N_parent) / (n + 1))) * p, f32, in this association; NaN compares Equal.
-__device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, uint32_t slot, int lane, uint32_t it, float c,
-                                            uint32_t quirks) {
+__device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t slot, int lane, uint32_t it,
+                                            float c, uint32_t quirks) {
     const size_t base = (size_t)slot * T.node_cap;
+    uint32_t* iflag = S.iter_flags + 2 * ((size_t)S.seg[slot] * G.iter_cap + it);    // this batch's flags of iteration `it`
     uint32_t node = 0, depth = 0;
     for (;;) {
         const uint32_t k = meta_nch(T.meta[base + node]);
@@ -133,19 +134,19 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, uint3
             backprop(T, base, node, v);
             S.leaf_term[slot] = 1;
             sc[SC_TERMINAL] += 1;
-            if (quirks && S.sel[slot] == kNone) atomicAdd(&S.iter_flags[2 * it + 1], 1u);
+            if (quirks && S.sel[slot] == kNone) atomicAdd(&iflag[1], 1u);
         } else {
             S.leaf_term[slot] = 0; S.leaf[slot] = node; S.sel[slot] = node;
-            S.iter_flags[2 * it] = 1u;                      // idempotent plain store (no same-address atomic storm)
+            iflag[0] = 1u;                                  // idempotent plain store (no same-address atomic storm)
             store_state(&S.eval_states[slot], st);
         }
     }
 }
 
-__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
+__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, float c, uint32_t quirks) {
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
-    select_slot(T, S, slot, (int)threadIdx.x, it, c, quirks);
+    select_slot(T, S, G, slot, (int)threadIdx.x, it, c, quirks);
 }
 
 // ---- expansion + backpropagation ---------------------------------------------------------------
@@ -162,8 +163,8 @@ constexpr uint32_t kRootIt = 0xFFFFFFFFu;
 // After the expansion the same wave immediately selects this game's leaf for iteration `next_it` (kNoNext = none):
 // one MCTS kernel per network evaluation instead of two.
 constexpr uint32_t kNoNext = 0xFFFFFFFEu;
-__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint32_t it, SearchParams P, uint32_t next_it,
-                                               float c) {
+__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
+                                               uint32_t next_it, float c) {
     __shared__ ExpandScratch sc;
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
@@ -171,9 +172,15 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
     const size_t base = (size_t)slot * T.node_cap;
     const bool root = it == kRootIt;
     const bool quirks = P.quirks != 0;
-    const bool active = root || S.iter_flags[2 * it] != 0;  // alpha_mcts.rs:170-172 `continue`
+    // the batch ("segment") of this slot: its seed, its flags, and its first slot (the reference's index 0)
+    const uint32_t seg = S.seg[slot];
+    const uint32_t seg_first = G.first_slot[seg];
+    const unsigned long long seed = G.seed[seg];
+    const uint32_t* iflag = root ? nullptr : S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
+    const bool active = root || iflag[0] != 0;              // alpha_mcts.rs:170-172 `continue`
     if (active) {
-    if (slot == 0 && lane == 0) atomicAdd(&S.counters[CNT_NN_EVALS], (unsigned long long)n);
+    // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
+    if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] += G.end_slot[seg] - seg_first;
 
     uint32_t node = 0;
     float v = 0.0f;
@@ -192,9 +199,9 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             v = value_head(S.hv + (size_t)slot * 72, S.wv, lane);       // the value head's FC + tanh (nn_device.h)
             if (lane == 0) S.sel_value[slot] = v;
         }
-    } else if (slot == 0) {
-        const float v0 = value_head(S.hv, S.wv, lane);
-        if (lane == 0) S.root_value0[0] = v0;
+    } else if (slot == seg_first) {
+        const float v0 = value_head(S.hv + (size_t)slot * 72, S.wv, lane);
+        if (lane == 0) S.root_value0[seg] = v0;
     }
     const uint32_t m0 = T.meta[base + node];
     if (do_expand && !(m0 & kDrained)) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
             const uint32_t code = bg_encode_dev(r0, r1, play);
             float p = softmax_prob(lrow[code], smM, smInv);
             if (root) {                                      // apply_dirichlet: (1-eps)*P + eps*noise
-                const float x = om * p, y = P.dir_eps * S.noise[code];
+                const float x = om * p, y = P.dir_eps * S.noise[(size_t)seg * 1352 + code];
                 p = x + y;
                 if (bg_decode_dev(r0, r1, player, code) != play) atomicAdd(&S.slot_cnt[slot * SC_COUNT + SC_ILLEGAL], 1u);
             }
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
                 const size_t ci = base + first + j;
                 BgState cs = st;
                 int d0, d1;
-                draw_dice(P.seed, gid, rnd, e, (uint32_t)j, d0, d1);    // child dice frozen at creation (Q9)
+                draw_dice(seed, gid, rnd, e, (uint32_t)j, d0, d1);      // child dice frozen at creation (Q9)
                 bg_apply_dev(cs, sc.ws.play[j], d0, d1);
                 store_state(&T.state[ci], cs);
                 T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = sc.raw[j] / sum;
@@ -253,29 +260,32 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, uint32_t n, uint
     __syncthreads();
     if (lane == 0) {
         if (do_backprop) backprop(T, base, node, v);
-        if (!root && quirks && slot == 0) {
+        if (!root && quirks && slot == seg_first) {
             // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
-            // i.e. this slot's root, with the NN value of its state
-            const uint32_t cnt = S.iter_flags[2 * it + 1];
-            const float rv = S.root_value0[0];
+            // i.e. the root in the batch's first slot, with the NN value of its state
+            const uint32_t cnt = iflag[1];
+            const float rv = S.root_value0[seg];
             for (uint32_t i = 0; i < cnt; ++i) { T.visits[base] += 1.0f; T.value[base] += rv; }
         }
     }
     }   // active
     if (next_it != kNoNext) {
         __syncthreads();                                    // lane 0's tree updates are visible to the whole wave
-        select_slot(T, S, slot, lane, next_it, c, P.quirks);
+        select_slot(T, S, G, slot, lane, next_it, c, P.quirks);
     }
 }
 
-// fold the per-slot counters of one move-step into the call totals (one block)
-__global__ __launch_bounds__(256) void k_reduce_counters(Slots S, uint32_t n) {
+// fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
+__global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
     __shared__ unsigned long long part[SC_COUNT][4];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t s0 = G.first_slot[seg], s1 = G.end_slot[seg];
+    if (s1 <= s0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long acc[SC_COUNT];
 #pragma unroll
     for (int c = 0; c < SC_COUNT; ++c) acc[c] = 0;
-    for (uint32_t s = tid; s < n; s += 256)
+    for (uint32_t s = s0 + tid; s < s1; s += 256)
 #pragma unroll
         for (int c = 0; c < SC_COUNT; ++c) {
             const unsigned long long v = S.slot_cnt[s * SC_COUNT + c];
@@ -293,11 +303,12 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Slots S, uint32_t n) {
     __syncthreads();
     if (tid == 0) {
         const int map[SC_COUNT] = {CNT_SELECTIONS, CNT_DEPTH_SUM, CNT_TERMINAL, CNT_EXPANSIONS, CNT_CHILDREN, CNT_MAX_CHILDREN, CNT_ILLEGAL};
+        unsigned long long* cnt = S.counters + (size_t)seg * CNT_COUNT;
         for (int c = 0; c < SC_COUNT; ++c) {
             unsigned long long t = 0;
             for (int w = 0; w < 4; ++w) t = c == SC_MAX_CHILDREN ? (part[c][w] > t ? part[c][w] : t) : t + part[c][w];
-            if (c == SC_MAX_CHILDREN) { if (t > S.counters[map[c]]) S.counters[map[c]] = t; }
-            else S.counters[map[c]] += t;
+            if (c == SC_MAX_CHILDREN) { if (t > cnt[map[c]]) cnt[map[c]] = t; }
+            else cnt[map[c]] += t;
         }
     }
 }
@@ -327,34 +338,42 @@ __global__ __launch_bounds__(64) void k_root_probs(Tree T, uint32_t n, float* __
 }
 
 // ---- self-play -----------------------------------------------------------------------------------
-// alpha_parallel.rs:103-111: T::new() + roll_die for every game
-__global__ void k_init_games(Games Gm, uint32_t n, uint32_t first_id, uint64_t seed) {
+// alpha_parallel.rs:103-111: T::new() + roll_die for every game of every batch
+__global__ void k_init_games(Games Gm, Segs G, uint32_t n) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
+    uint32_t seg = 0;
+    while (seg + 1 < G.n && g >= G.game0[seg + 1]) ++seg;
     BgState s;
     // Backgammon::new, backgammon_logic.rs:80-94
     s.w[0] = 0x00000002u; s.w[1] = 0xFD00FB00u; s.w[2] = 0x05000000u; s.w[3] = 0x000000FBu;
     s.w[4] = 0x00050003u; s.w[5] = 0xFE000000u; s.w[6] = 0u;
     int d0, d1;
-    draw_dice(seed, first_id + g, 0u, kTagInitRoll, 0u, d0, d1);
+    draw_dice(G.seed[seg], G.first_id[seg] + (g - G.game0[seg]), 0u, kTagInitRoll, 0u, d0, d1);
     s.w[7] = (uint32_t)d0 | ((uint32_t)d1 << 8) | (0xFFu << 16);
     store_state(&Gm.state[g], s);
     Gm.rounds[g] = 0; Gm.nfrags[g] = 0; Gm.alive[g] = 1; Gm.winner[g] = 0;
     Gm.ev_a_count[g] = kNone; Gm.ev_b_count[g] = kNone; Gm.ev_a_step[g] = 0; Gm.ev_b_step[g] = 0;
-    Gm.live[g] = g;
+    Gm.live[g] = g; Gm.seg[g] = (uint8_t)seg;
 }
 
-__global__ void k_gather_roots(Games Gm, Slots S, uint32_t n_live, uint32_t first_id) {
+// live games -> slots; the live list is ascending in the game index, so the slots of a batch are contiguous: the
+// slot whose predecessor belongs to another batch is the batch's first (the reference's index 0), likewise its end
+__global__ void k_gather_roots(Games Gm, Slots S, Segs G, uint32_t n_live) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_live) return;
     const uint32_t g = Gm.live[slot];
+    const uint32_t seg = Gm.seg[g];
     store_state(&S.roots[slot], load_state(&Gm.state[g]));
-    S.game_id[slot] = first_id + g;
+    S.game_id[slot] = G.first_id[seg] + (g - G.game0[seg]);
     S.round[slot] = Gm.rounds[g];
+    S.seg[slot] = seg;
+    if (slot == 0 || Gm.seg[Gm.live[slot - 1]] != seg) G.first_slot[seg] = slot;
+    if (slot + 1 == n_live || Gm.seg[Gm.live[slot + 1]] != seg) G.end_slot[seg] = slot + 1;
 }
 
 // the body of the per-game loop of self_play_parallel, alpha_parallel.rs:168-224
-__global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_live, uint32_t step, PlayParams P) {
+__global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, Segs G, uint32_t n_live, uint32_t step, PlayParams P) {
     __shared__ float row[1352];
     __shared__ float sum_s;
     __shared__ int chosen_s;
@@ -366,7 +385,10 @@ __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_l
     const uint32_t k = meta_nch(T.meta[base]), fc = T.first_child[base];
     BgState s = load_state(&Gm.state[g]);
     const uint32_t round = Gm.rounds[g];
-    const uint32_t gid = P.first_id + g;
+    const uint32_t seg = Gm.seg[g];
+    const uint32_t gid = G.first_id[seg] + (g - G.game0[seg]);
+    const unsigned long long seed = G.seed[seg];
+    unsigned long long* cnt = Gm.counters + (size_t)seg * CNT_COUNT;
     bool removed = false, flushed = false;
     if (round >= P.round_limit) {                               // :172-180 (no `continue`)
         if (lane == 0) { Gm.ev_a_count[g] = Gm.nfrags[g]; Gm.ev_a_step[g] = step; }
@@ -375,12 +397,12 @@ __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_l
     if (k == 0) {                                               // :183-189 skip_turn
         if (lane == 0) {
             int d0, d1;
-            draw_dice(P.seed, gid, round, kTagMoveRoll, 0u, d0, d1);
+            draw_dice(seed, gid, round, kTagMoveRoll, 0u, d0, d1);
             bg_skip_dev(s, d0, d1);
             store_state(&Gm.state[g], s);
             Gm.rounds[g] = round + 1;
-            if (removed) Gm.alive[g] = 0;
-            atomicAdd(&Gm.counters[CNT_PLIES], 1ull);
+            if (removed) { Gm.alive[g] = 0; atomicAdd(&cnt[CNT_GAMES], 1ull); }
+            atomicAdd(&cnt[CNT_PLIES], 1ull);
         }
         return;
     }
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_l
     if (lane == 0) {
         double total = 0.0;
         for (int a = 0; a < 1352; ++a) total += (double)row[a];
-        const double x = draw_uniform(P.seed, gid, round, kTagSample, 0u) * total;
+        const double x = draw_uniform(seed, gid, round, kTagSample, 0u) * total;
         double cum = 0.0;
         int pick = -1, last_nz = 0;
         for (int a = 0; a < 1352; ++a) {
@@ -423,33 +445,36 @@ __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, uint32_t n_l
         // decode + apply_move (:202-210); legality of decode(code) is checked when the root is expanded
         const uint32_t play = bg_decode_dev(st_roll(s, 0), st_roll(s, 1), st_player(s), code);
         int d0, d1;
-        draw_dice(P.seed, gid, round, kTagMoveRoll, 0u, d0, d1);
+        draw_dice(seed, gid, round, kTagMoveRoll, 0u, d0, d1);
         bg_apply_dev(s, play, d0, d1);
         store_state(&Gm.state[g], s);
         Gm.rounds[g] = round + 1;                               // :213
-        atomicAdd(&Gm.counters[CNT_PLIES], 1ull);
+        atomicAdd(&cnt[CNT_PLIES], 1ull);
         const int w = bg_winner_dev(s);
         if (w != 0) {                                           // :215-223
             if (!(flushed && !P.quirks)) { Gm.ev_b_count[g] = nf + 1; Gm.ev_b_step[g] = step; }
             Gm.winner[g] = (int8_t)w;
             removed = true;
         }
-        if (removed) { Gm.alive[g] = 0; atomicAdd(&Gm.counters[CNT_GAMES], 1ull); }
+        if (removed) { Gm.alive[g] = 0; atomicAdd(&cnt[CNT_GAMES], 1ull); }
     }
 }
 
-// stable compaction of the live list (one block)
-__global__ __launch_bounds__(1024) void k_compact_live(Games Gm, uint32_t n_live, uint32_t* n_live_out) {
+// stable compaction of the live list (one block); n_live_out[0] = games alive, [1 + b] = alive in batch b
+__global__ __launch_bounds__(1024) void k_compact_live(Games Gm, uint32_t n_live, uint32_t n_segs, uint32_t* n_live_out) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
+    __shared__ uint32_t per_seg[kMaxSegments];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
+    if (tid < (int)kMaxSegments) per_seg[tid] = 0;
     __syncthreads();
     for (uint32_t c0 = 0; c0 < n_live; c0 += 1024) {
         const uint32_t i = c0 + tid;
         uint32_t g = 0;
         bool keep = false;
         if (i < n_live) { g = Gm.live[i]; keep = Gm.alive[g] != 0; }
+        if (keep) atomicAdd(&per_seg[Gm.seg[g]], 1u);
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -462,7 +487,8 @@ __global__ __launch_bounds__(1024) void k_compact_live(Games Gm, uint32_t n_live
         if (tid == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; carry += t; }
         __syncthreads();
     }
-    if (tid == 0) *n_live_out = carry;
+    if (tid == 0) n_live_out[0] = carry;
+    if (tid < (int)n_segs) n_live_out[1 + tid] = per_seg[tid];
 }
 
 // gather fragments into the output order the host computed: src = g*frag_cap + r
@@ -479,30 +505,30 @@ __global__ void k_gather_frags(Games Gm, const uint32_t* __restrict__ src, uint3
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n) {
     hipLaunchKernelGGL(k_init_roots, dim3((n + 255) / 256), dim3(256), 0, st, T, S, n);
 }
-void launch_select(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, float c, uint32_t quirks) {
-    hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, n, it, c, quirks);
+void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks) {
+    hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, G, n, it, c, quirks);
 }
-void launch_expand(hipStream_t st, const Tree& T, const Slots& S, uint32_t n, uint32_t it, const SearchParams& P,
+void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c) {
-    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, n, it, P, next_it, c);
+    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
 }
-void launch_reduce_counters(hipStream_t st, const Slots& S, uint32_t n) {
-    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(256), 0, st, S, n);
+void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
+    hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);
 }
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits) {
     hipLaunchKernelGGL(k_root_probs, dim3(n), dim3(64), 0, st, T, n, probs, nch, root_visits);
 }
-void launch_init_games(hipStream_t st, const Games& G, uint32_t n, uint32_t first_id, uint64_t seed) {
-    hipLaunchKernelGGL(k_init_games, dim3((n + 255) / 256), dim3(256), 0, st, G, n, first_id, seed);
+void launch_init_games(hipStream_t st, const Games& Gm, const Segs& G, uint32_t n) {
+    hipLaunchKernelGGL(k_init_games, dim3((n + 255) / 256), dim3(256), 0, st, Gm, G, n);
 }
-void launch_gather_roots(hipStream_t st, const Games& G, const Slots& S, uint32_t n_live, uint32_t first_id) {
-    hipLaunchKernelGGL(k_gather_roots, dim3((n_live + 255) / 256), dim3(256), 0, st, G, S, n_live, first_id);
+void launch_gather_roots(hipStream_t st, const Games& Gm, const Slots& S, const Segs& G, uint32_t n_live) {
+    hipLaunchKernelGGL(k_gather_roots, dim3((n_live + 255) / 256), dim3(256), 0, st, Gm, S, G, n_live);
 }
-void launch_play_move(hipStream_t st, const Tree& T, const Games& G, uint32_t n_live, uint32_t step, const PlayParams& P) {
-    hipLaunchKernelGGL(k_play_move, dim3(n_live), dim3(64), 0, st, T, G, n_live, step, P);
+void launch_play_move(hipStream_t st, const Tree& T, const Games& Gm, const Segs& G, uint32_t n_live, uint32_t step, const PlayParams& P) {
+    hipLaunchKernelGGL(k_play_move, dim3(n_live), dim3(64), 0, st, T, Gm, G, n_live, step, P);
 }
-void launch_compact_live(hipStream_t st, const Games& G, uint32_t n_live, uint32_t* n_live_out) {
-    hipLaunchKernelGGL(k_compact_live, dim3(1), dim3(1024), 0, st, G, n_live, n_live_out);
+void launch_compact_live(hipStream_t st, const Games& Gm, uint32_t n_live, uint32_t n_segs, uint32_t* n_live_out) {
+    hipLaunchKernelGGL(k_compact_live, dim3(1), dim3(1024), 0, st, Gm, n_live, n_segs, n_live_out);
 }
 void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes) {
     if (!n) return;

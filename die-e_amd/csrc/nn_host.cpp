@@ -281,7 +281,7 @@ void nn_reset_cluster(Engine& e) {
 
 // small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
 // would not be co-resident on this device: the caller runs the per-layer kernels.
-static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states) {
+static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, uint16_t* actX, uint16_t* actH) {
     const void* winit = W.wconv[0].p; const float* binit = W.bconv[0].p;
     for (const auto& r : W.cluster_table) {
         if (G > r.max_games) continue;
@@ -290,25 +290,31 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states) {
             HIPCHK(hipMemsetAsync(W.cl_sync.p, 0, (size_t)kClusterMaxGroups * 32 * sizeof(uint32_t), e.stream));
         }
         ClusterBaton* bt = (e.device >= 0 && e.device < 16) ? &g_baton[e.device] : nullptr;
-        if (bt && bt->engines > 1) {
-            std::lock_guard<std::mutex> lk(bt->mu);
-            if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
-            else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
-            const bool ok = launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
-            if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
-            return ok;
+        if (bt) {
+            std::unique_lock<std::mutex> lk(bt->mu);
+            if (bt->engines > 1) {
+                if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
+                else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
+                const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
+                if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
+                return ok;
+            }
         }
-        return launch_tower_cluster(e.stream, r.boards_per_group, W.actX.p, W.actH.p, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
+        return launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
     }
     return false;
 }
 
-void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev) {
-    if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
-    if (G <= 0) return;
+// the convolutional part of the network (init block, 38-layer tower, head convs) for rows [off, off + G) of the batch:
+// states -> hp / hv.  The tower kernel is picked by G alone (tower_table / cluster_table).
+static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G) {
     NetWeights& W = *e.net;
-    nn_reserve(e, G);
     hipStream_t st = e.stream;
+    const void* states_dev = (const uint8_t*)states_all + (size_t)off * 32;
+    uint16_t* actX = W.actX.p + (size_t)off * 24 * 256;
+    uint16_t* actH = W.actH.p + (size_t)off * 24 * 256;
+    uint16_t* hp = W.hp.p + (size_t)off * 768;
+    float* hv = W.hv.p + (size_t)off * 72;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
     const int tgeom = W.tower_geometry_for(G);
     static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
@@ -320,20 +326,25 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     auto stamp0 = [&] { if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); } };
     // the init block reads the states and builds the input planes itself (no separate planes kernel)
     auto init_block = [&] {
-        launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, W.actX.p, nullptr, G, 256);
+        launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, actX, nullptr, G, 256);
+    };
+    auto cluster = [&](const void* states) {
+        const bool ok = cluster_tower(e, W, G, states, actX, actH);
+        if (ok) W.cluster_used = true;
+        return ok;
     };
     bool done = false, heads_done = false;
     if (tgeom < 0 && !W.cluster_table.empty() && W.cluster_init) {
         // small batches: init block + all 38 layers in ONE launch, 8-workgroup clusters per board group
         stamp0();
-        if (cluster_tower(e, W, G, states_dev)) { kind = 2; done = true; }
+        if (cluster(states_dev)) { kind = 2; done = true; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
     if (!done && !whole && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
         // large batches: init block + all 38 layers in one launch, activations stay in LDS
         stamp0();
-        launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G, states_dev, W.winit16.p, W.bconv[0].p,
-                     W.fused_heads ? W.whead16.p : nullptr, W.bconv[39].p, W.hp.p, W.hv.p);
+        launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G, states_dev, W.winit16.p, W.bconv[0].p,
+                     W.fused_heads ? W.whead16.p : nullptr, W.bconv[39].p, hp, hv);
         done = true; heads_done = W.fused_heads;
     }
     if (!done) {
@@ -341,31 +352,73 @@ void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         if (!ev0) stamp0();
         if (whole) {
             launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
-                         W.hp.p, W.hv.p, G);
+                         hp, hv, G);
         } else if (tgeom >= 0) {
-            launch_tower(st, tgeom, W.actX.p, W.wtower.p, W.wtower16.p, W.btower.p, W.actX.p, G);   // all 38 layers, activations stay in LDS
-        } else if (cluster_tower(e, W, G, nullptr)) {
+            launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G);   // all 38 layers, activations stay in LDS
+        } else if (cluster(nullptr)) {
             kind = 2;                                                   // (init block launched separately: DIEE_CLUSTER_INIT=0)
         } else {
             kind = 0;
             for (int i = 0; i < BLOCKS; ++i) {
-                launch_conv3x3(st, 256, 0, W.actX.p, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, W.actH.p, nullptr, G, 256);
+                launch_conv3x3(st, 256, 0, actX, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, actH, nullptr, G, 256);
                 // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
-                launch_conv3x3(st, 256, 1, W.actH.p, W.wl(2 + 2 * i), W.bl(2 + 2 * i), W.actX.p, W.actX.p, nullptr, G, 256);
+                launch_conv3x3(st, 256, 1, actH, W.wl(2 + 2 * i), W.bl(2 + 2 * i), actX, actX, nullptr, G, 256);
             }
         }
     }
     if (trace_dispatch)
-        fprintf(stderr, "[diee] forward of %d boards: %s (fused geometry %d, conv variant table entries %zu / %zu)\n", G,
+        fprintf(stderr, "[diee] forward of boards %d..%d: %s (fused geometry %d, conv variant table entries %zu / %zu)\n", off, off + G,
                 kind == 1 ? "fused tower" : kind == 2 ? "cluster tower" : "per-layer kernels", tgeom, W.tower_table.size(), W.cluster_table.size());
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind});
     }
-    if (!whole && !heads_done) launch_conv3x3(st, 256, 2, W.actX.p, W.wconv[39].p, W.bconv[39].p, nullptr, W.hp.p, W.hv.p, G, 64);
+    if (!whole && !heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
+}
+
+// forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
+// More boards than one pass of the chip holds (256 CUs x 4 boards): the whole multiples of kFullChip go through ONE
+// launch of the 4-board fused tower (its workgroups run in full rounds), the remainder through the kernel that is
+// fastest at the remainder's size -- a partial last round of 4-board workgroups would cost a full round.
+void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev) {
+    if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    if (G <= 0) return;
+    NetWeights& W = *e.net;
+    nn_reserve(e, G);
+    hipStream_t st = e.stream;
+    const int full = W.full_chip_boards;
+    int main_rows = G;
+    if (full > 0 && G > full && W.tower_geometry_for(G) >= 0) {
+        main_rows = G / full * full;
+        if (W.tower_geometry_for(G - main_rows) == W.tower_geometry_for(G)) main_rows = G;   // the remainder would take the same kernel
+    }
+    nn_conv_chunk(e, states_dev, 0, main_rows);
+    if (main_rows < G) nn_conv_chunk(e, states_dev, main_rows, G - main_rows);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
     if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
+}
+
+// the cluster tower ran since the last call (its hand-over flag is worth a look)
+bool nn_cluster_used(Engine& e) {
+    if (!e.net) return false;
+    const bool u = e.net->cluster_used;
+    e.net->cluster_used = false;
+    return u;
+}
+
+// a cluster hand-over starved: never launch the cluster tower again in this process (batches it took run on the
+// per-layer kernels), clear the flag bit and re-arm the hand-over counters
+void nn_disable_cluster(Engine& e) {
+    if (!e.net) return;
+    e.net->cluster_table.clear();
+    uint32_t f = 0;
+    e.d2h(&f, e.flags_dev.p, 1);
+    e.sync();
+    f &= ~4u;
+    e.h2d(e.flags_dev.p, &f, 1);
+    e.sync();
+    nn_reset_cluster(e);
 }
 
 NetHeads nn_heads(Engine& e, int G) {

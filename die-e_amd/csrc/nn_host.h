@@ -25,9 +25,10 @@ struct NetWeights {
     // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
     std::vector<TowerRule> tower_table = {{928, 8}, {416, 6}, {256, 3}};
+    bool invariant = false;         // DIEE_FLAG_INVARIANT_NN / diee_set_invariant_nn: every batch size on the fused 16x16x32 tower
     int tower_geometry_for(int G) const {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
-        return -1;
+        return invariant ? 3 : -1;  // 3 = k_tower16<2 boards, 8 waves>: same arithmetic per output element as the 4-board geometries
     }
     // cluster tower (k_tower_cl): batches of at most max_games boards run the 38 layers in one launch, boards_per_group
     // boards per 8-workgroup cluster (1, 2, 4: K split over 8 waves; 8: over 4 waves); tried in order, a batch no rule
@@ -36,6 +37,9 @@ struct NetWeights {
     struct ClusterRule { int max_games, boards_per_group; };
     std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}, {256, 8}};
     DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
+    bool cluster_used = false;      // a cluster launch went out since nn_cluster_used() was asked last
+    int full_chip_boards = 1024;    // one pass of the chip through the 4-board fused tower (256 CUs x 4 boards); batches above
+                                    // it run whole multiples in one launch and the remainder in a launch of its own (0: never split)
     bool fused_heads = true;        // the fused tower runs the head convs itself (its output tile never leaves the CU)
     bool cluster_init = true;       // the cluster tower runs the init block itself (every workgroup, for its cluster's boards)
     DevBuf<uint16_t> wfc;           // policy FC fragments
@@ -69,6 +73,9 @@ void nn_reserve(Engine& e, int G);
 void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev);
 struct NetHeads { const float* logits; const float* hv; const float* wv; };
 NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserved
+bool nn_cluster_used(Engine& e);
+void nn_disable_cluster(Engine& e);
+void nn_reset_cluster(Engine& e);
 void nn_harvest(Engine& e, diee_stats* stats);
 void nn_reset_timing(Engine& e);
 void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward);

@@ -1410,18 +1410,19 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 // cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
 // runs the per-layer path)
 template <int GT, int NSPLIT>
-static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
+static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
-    static int capacity = -1;
+    static int capacity_of[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};     // per device
+    int& capacity = capacity_of[device & 15];
     if (capacity < 0) {
         (void)hipFuncSetAttribute((const void*)k_tower_cl<GT, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         // one workgroup per CU is always admitted (the occupancy API is not asked: with 160 KB of dynamic LDS
         // it answers 0 under some runtimes), and no geometry here needs more than one per CU
-        int dev = 0, cus = 0;
-        capacity = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? cus : 0;
+        int cus = 0;
+        capacity = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? cus : 0;
     }
     const int groups = (G + GT - 1) / GT;
     const int grid = 64 * ((groups + 7) / 8);
@@ -1435,13 +1436,13 @@ static bool tower_cl_launch(hipStream_t st, uint16_t* X, uint16_t* H, const void
                        (const BgState*)states, (const u32x4*)winit, binit);
     return true;
 }
-bool launch_tower_cluster(hipStream_t st, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
+bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
     switch (boards_per_group) {
-        case 1: return tower_cl_launch<1, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 2: return tower_cl_launch<2, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 4: return tower_cl_launch<4, 8>(st, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 8: return tower_cl_launch<8, 4>(st, X, H, wt, bias, G, sync, err, states, winit, binit);     // K split over 4 waves (one per SIMD)
+        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
+        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }

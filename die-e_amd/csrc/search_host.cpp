@@ -25,22 +25,31 @@ struct SearchBufs {
     uint32_t node_cap = 0, slot_cap = 0;
     // slots
     DevBuf<BgState> roots, eval_states;
-    DevBuf<uint32_t> game_id, round, leaf, sel, iter_flags;
+    DevBuf<uint32_t> game_id, round, seg, leaf, sel, iter_flags;
     DevBuf<float> sel_value, noise, root_value0;
     DevBuf<uint8_t> leaf_term;
-    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
+    // batches ("segments") in flight
+    DevBuf<unsigned long long> seg_seed;
+    DevBuf<uint32_t> seg_first_id, seg_game0, seg_slots;      // seg_slots = first_slot[kMaxSegments] ++ end_slot[kMaxSegments]
+    float* noise_host = nullptr;                               // pinned, [2][kMaxSegments][1352]: upload without a sync
+    uint32_t* live_host = nullptr;                             // pinned, [2 + kMaxSegments]: n_live, per-batch live, flag word
     // games
     DevBuf<BgState> gstate;
     DevBuf<uint32_t> rounds, nfrags, ev_a_count, ev_a_step, ev_b_count, ev_b_step, live, n_live_dev;
-    DevBuf<uint8_t> alive;
+    DevBuf<uint8_t> alive, gseg;
     DevBuf<int8_t> winner, frag_player;
     DevBuf<float> frag_ps, frag_planes;
     uint32_t game_cap = 0, frag_cap = 0;
     // output staging
     DevBuf<uint32_t> out_src;
     DevBuf<float> out_ps, out_planes;
+    ~SearchBufs() {
+        if (noise_host) (void)hipHostFree(noise_host);
+        if (live_host) (void)hipHostFree(live_host);
+    }
 };
 
 void free_search(SearchBufs* s) { delete s; }
@@ -103,12 +112,20 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.visits.ensure(N); B.value.ensure(N); B.prior.ensure(N);
         B.parent.ensure(N); B.first_child.ensure(N); B.meta.ensure(N); B.nstate.ensure(N);
         B.used.ensure(sc);
-        B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc);
+        B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc); B.seg.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
-        B.noise.ensure(1352); B.root_value0.ensure(4); B.counters.ensure(CNT_COUNT); B.slot_cnt.ensure((size_t)sc * SC_COUNT);
+        B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
     }
-    if (iterations + 1 > B.iter_cap) { B.iter_flags.ensure(2 * ((size_t)iterations + 1)); B.iter_cap = iterations + 1; }
+    if (!B.noise.p) {
+        B.noise.ensure((size_t)kMaxSegments * 1352); B.root_value0.ensure(kMaxSegments);
+        B.counters.ensure((size_t)kMaxSegments * CNT_COUNT); B.counters_bak.ensure((size_t)kMaxSegments * CNT_COUNT);
+        B.seg_seed.ensure(kMaxSegments); B.seg_first_id.ensure(kMaxSegments); B.seg_game0.ensure(kMaxSegments);
+        B.seg_slots.ensure(2 * kMaxSegments); B.n_live_dev.ensure(2 + kMaxSegments);
+        HIPCHK(hipHostMalloc((void**)&B.noise_host, sizeof(float) * 2 * kMaxSegments * 1352));
+        HIPCHK(hipHostMalloc((void**)&B.live_host, sizeof(uint32_t) * (2 + kMaxSegments)));
+    }
+    if (iterations + 1 > B.iter_cap) { B.iter_flags.ensure((size_t)kMaxSegments * 2 * ((size_t)iterations + 1)); B.iter_cap = iterations + 1; }
 }
 
 Tree tree_view(SearchBufs& B) {
@@ -116,45 +133,100 @@ Tree tree_view(SearchBufs& B) {
 }
 Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
-    return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
+    return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
                  H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
 }
+Segs segs_view(SearchBufs& B, uint32_t n_segs) {
+    return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};
+}
 
-// alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round
-void mcts_run(Engine& e, uint32_t n, const diee_mcts_cfg& cfg, uint64_t seed, uint32_t step, uint32_t flags) {
+// the batches ("segments") of a call: seeds, RNG keys of their first games, positions of their first games
+void upload_segments(Engine& e, const std::vector<diee_batch>& bt) {
+    SearchBufs& B = *e.search;
+    std::vector<unsigned long long> seeds(bt.size());
+    std::vector<uint32_t> first(bt.size()), game0(bt.size());
+    uint32_t g = 0;
+    for (size_t k = 0; k < bt.size(); ++k) { seeds[k] = bt[k].seed; first[k] = bt[k].first_game_id; game0[k] = g; g += bt[k].n_games; }
+    e.h2d(B.seg_seed.p, seeds.data(), seeds.size());
+    e.h2d(B.seg_first_id.p, first.data(), first.size());
+    e.h2d(B.seg_game0.p, game0.data(), game0.size());
+    HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * kMaxSegments * CNT_COUNT, e.stream));
+    e.sync();                                                          // the vectors are stack-scoped
+}
+
+// one Dirichlet sample per batch and move-step (noise.rs:27-34), drawn on the host into pinned buffer `buf`
+void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint32_t step, float alpha) {
+    for (size_t k = 0; k < bt.size(); ++k)
+        dirichlet_host(bt[k].seed, step, alpha, 1352, B.noise_host + ((size_t)buf * kMaxSegments + k) * 1352);
+}
+
+// alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round / seg (segment table uploaded, the
+// Dirichlet samples of this move-step in pinned buffer `buf`).  Enqueues only: no host synchronisation.
+void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, int buf, uint32_t flags) {
     SearchBufs& B = *e.search;
     const Tree T = tree_view(B);
     const Slots S = slots_view(e, B);
+    const Segs G = segs_view(B, n_segs);
     hipStream_t st = e.stream;
     const uint32_t quirks = (flags & DIEE_FLAG_REF_QUIRKS) ? 1u : 0u;
-    if (cfg.iterations) HIPCHK(hipMemsetAsync(B.iter_flags.p, 0, sizeof(uint32_t) * 2 * (size_t)cfg.iterations, st));
-    float noise[1352];
-    dirichlet_host(seed, step, cfg.dir_alpha, 1352, noise);          // noise.rs:27-34: one sample per move-step
-    HIPCHK(hipMemcpyAsync(B.noise.p, noise, sizeof noise, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                                // `noise` is a stack buffer
+    HIPCHK(hipMemsetAsync(B.iter_flags.p, 0, sizeof(uint32_t) * 2 * (size_t)B.iter_cap * n_segs, st));
+    HIPCHK(hipMemcpyAsync(B.noise.p, B.noise_host + (size_t)buf * kMaxSegments * 1352, sizeof(float) * 1352 * n_segs,
+                          hipMemcpyHostToDevice, st));
     launch_init_roots(st, T, S, n);
     nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);        // forward_policy, alpha_mcts.rs:104 (softmax / tanh in k_expand)
-    const SearchParams P{seed, cfg.dir_eps, quirks};
+    const SearchParams P{cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
-    launch_expand(st, T, S, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
+    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
         nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);       // alpha_mcts.rs:186
-        launch_expand(st, T, S, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
+        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
     }
-    launch_reduce_counters(st, S, n);
+    launch_reduce_counters(st, S, G);
     HIPCHK(hipGetLastError());
 }
 
-void read_counters(Engine& e, diee_stats* stats) {
+// a starved in-launch hand-over of the cluster tower (another process on the GPU took its CUs) raises bit 2 of the
+// flag word: the tower then finished "dead" and this search is garbage.  Detected before the move is played: the
+// cluster table is dropped for the rest of the process and the caller repeats the search on the per-layer kernels.
+bool cluster_starved(Engine& e) {
+    if (!e.net || !nn_cluster_used(e)) return false;
+    SearchBufs& B = *e.search;
+    e.d2h(B.live_host + 1 + kMaxSegments, e.flags_dev.p, 1);
+    e.sync();
+    if (!(B.live_host[1 + kMaxSegments] & 4u)) return false;
+    nn_disable_cluster(e);                                            // clears the flag bit and re-arms the counters
+    fprintf(stderr, "[diee] cluster tower: a workgroup hand-over starved (is another process using this GPU?); "
+                    "falling back to the per-layer kernels for the rest of this process\n");
+    return true;
+}
+
+void read_counters(Engine& e, uint32_t seg, diee_stats* stats) {
     if (!stats) return;
     unsigned long long c[CNT_COUNT];
-    e.d2h(c, e.search->counters.p, (size_t)CNT_COUNT);
+    e.d2h(c, e.search->counters.p + (size_t)seg * CNT_COUNT, (size_t)CNT_COUNT);
     e.sync();
     stats->nn_evals = c[CNT_NN_EVALS]; stats->expansions = c[CNT_EXPANSIONS]; stats->children = c[CNT_CHILDREN];
     stats->terminal_hits = c[CNT_TERMINAL]; stats->depth_sum = c[CNT_DEPTH_SUM]; stats->selections = c[CNT_SELECTIONS];
     stats->illegal_decodes = c[CNT_ILLEGAL]; stats->max_children = c[CNT_MAX_CHILDREN];
     stats->plies = c[CNT_PLIES]; stats->games = c[CNT_GAMES];
 }
+
+struct InvariantScope {    // DIEE_FLAG_INVARIANT_NN for the duration of one call
+    NetWeights* w; bool saved;
+    InvariantScope(Engine& e, uint32_t flags) : w(e.net), saved(e.net->invariant) { if (flags & DIEE_FLAG_INVARIANT_NN) w->invariant = true; }
+    ~InvariantScope() { w->invariant = saved; }
+};
+
+struct FragBufs {          // host arrays of one diee_fragments until they are handed over
+    int8_t* outcome = nullptr; float* ps = nullptr; float* state = nullptr; uint32_t* game = nullptr;
+    bool alloc(size_t n) {
+        outcome = (int8_t*)malloc(n ? n : 1); ps = (float*)malloc((n ? n : 1) * 1352 * sizeof(float));
+        state = (float*)malloc((n ? n : 1) * 144 * sizeof(float)); game = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+        return outcome && ps && state && game;
+    }
+    void release(diee_fragments* f, uint32_t n) { f->n = n; f->outcome = outcome; f->ps = ps; f->state = state; f->game = game; outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; }
+    ~FragBufs() { free(outcome); free(ps); free(state); free(game); }
+};
 
 }  // namespace
 
@@ -168,16 +240,28 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     for (uint32_t i = 0; i < n; ++i)
         if (roots[i].roll[0] == 0 && roots[i].roll[1] == 0) throw EngineError(DIEE_ERR_ARG, "die has not been rolled (backgammon_logic.rs:404)");
     reserve_search(*this, n, cfg->iterations);
+    nn_reserve(*this, (int)n);
     SearchBufs& B = *search;
+    const InvariantScope inv(*this, flags);
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> ids(n), rds(n);
     for (uint32_t i = 0; i < n; ++i) { ids[i] = game_ids ? game_ids[i] : i; rds[i] = rounds ? rounds[i] : 0; }
+    // the roots are ONE batch (one alpha_mcts_parallel call): a single segment spanning every slot
+    const std::vector<diee_batch> one{{n, 0u, seed}};
+    upload_segments(*this, one);
+    const uint32_t span[2] = {0u, n};
+    h2d(B.seg_slots.p, &span[0], 1); h2d(B.seg_slots.p + kMaxSegments, &span[1], 1);
+    HIPCHK(hipMemsetAsync(B.seg.p, 0, sizeof(uint32_t) * n, stream));
     h2d((uint8_t*)B.roots.p, (const uint8_t*)roots, (size_t)n * 32);
     h2d(B.game_id.p, ids.data(), (size_t)n); h2d(B.round.p, rds.data(), (size_t)n);
-    HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
     sync();
     const int se = net->sample_every; net->sample_every = 0;
-    mcts_run(*this, n, *cfg, seed, step, flags);
+    draw_noise(B, 0, one, step, cfg->dir_alpha);
+    mcts_run(*this, n, 1, *cfg, 0, flags);
+    if (cluster_starved(*this)) {                                   // repeat on the per-layer kernels
+        HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
+        mcts_run(*this, n, 1, *cfg, 0, flags);
+    }
     net->sample_every = se;
     tmp_a.ensure((size_t)n * 1352 * 4); tmp_b.ensure((size_t)n * 4); tmp_c.ensure((size_t)n * 4);
     launch_root_probs(stream, tree_view(B), n, (float*)tmp_a.p, (uint32_t*)tmp_b.p, (float*)tmp_c.p);
@@ -187,7 +271,7 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     if (root_visits) d2h((uint8_t*)root_visits, tmp_c.p, (size_t)n * 4);
     sync();
     if (stats) {
-        read_counters(*this, stats);
+        read_counters(*this, 0, stats);
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     check_overflow();
@@ -195,60 +279,102 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
 
 void Engine::self_play(uint32_t n_games, uint32_t first_game_id, const diee_mcts_cfg* cfg, float temperature,
                        uint64_t seed, uint32_t flags, uint32_t max_steps, diee_fragments* out, diee_stats* stats) {
+    const diee_batch one{n_games, first_game_id, seed};
+    self_play_multi(&one, 1, cfg, temperature, flags, max_steps, out, stats);
+}
+
+// K calls of self_play_parallel (alpha_parallel.rs:101-231) played side by side: every batch starts at move-step 0,
+// the slot space holds the live games of batch 0, then of batch 1, ..., and every network launch evaluates them all.
+// Each batch keeps its own seed, Dirichlet stream, `node_selected` flags and slot-0 bookkeeping, so what a batch
+// produces depends on the other batches only through the network kernel its rows are evaluated by.
+void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, const diee_mcts_cfg* cfg, float temperature,
+                             uint32_t flags, uint32_t max_steps, diee_fragments* outs, diee_stats* stats) {
     HIPCHK(hipSetDevice(device));
     if (!net || !net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
-    if (out) memset(out, 0, sizeof *out);
-    if (stats) memset(stats, 0, sizeof *stats);
+    if (outs) memset(outs, 0, sizeof(diee_fragments) * n_batches);
+    if (stats) memset(stats, 0, sizeof(diee_stats) * n_batches);
     if (cfg->iterations == 0) throw EngineError(DIEE_ERR_ARG, "iterations must be >= 1");
+    if (n_batches == 0 || n_batches > kMaxSegments) throw EngineError(DIEE_ERR_ARG, "1 .. 64 batches per call");
+    const std::vector<diee_batch> bt(batches, batches + n_batches);
+    std::vector<uint32_t> game0(n_batches);
+    uint64_t total_games = 0;
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        if (bt[k].n_games == 0) throw EngineError(DIEE_ERR_ARG, "a batch needs at least one game");
+        game0[k] = (uint32_t)total_games; total_games += bt[k].n_games;
+    }
+    if (total_games > (1u << 22)) throw EngineError(DIEE_ERR_ARG, "too many games in flight");
+    const uint32_t n_games = (uint32_t)total_games;
     reserve_search(*this, n_games, cfg->iterations);
     nn_reserve(*this, (int)n_games);
     SearchBufs& B = *search;
+    const InvariantScope inv(*this, flags);
     const uint32_t frag_cap = cfg->round_limit + 2;
     if (n_games > B.game_cap || frag_cap > B.frag_cap) {
         const uint32_t gc = std::max(n_games, B.game_cap), fc = std::max(frag_cap, B.frag_cap);
         B.gstate.ensure(gc); B.rounds.ensure(gc); B.nfrags.ensure(gc); B.alive.ensure(gc); B.winner.ensure(gc);
         B.ev_a_count.ensure(gc); B.ev_a_step.ensure(gc); B.ev_b_count.ensure(gc); B.ev_b_step.ensure(gc);
-        B.live.ensure(gc); B.n_live_dev.ensure(4);
+        B.live.ensure(gc); B.gseg.ensure(gc);
         B.frag_ps.ensure((size_t)gc * fc * 1352); B.frag_planes.ensure((size_t)gc * fc * 144);
         B.frag_player.ensure((size_t)gc * fc);
         B.game_cap = gc; B.frag_cap = fc;
     }
     const Games Gm{B.gstate.p, B.rounds.p, B.nfrags.p, B.alive.p, B.winner.p, B.ev_a_count.p, B.ev_a_step.p,
-                   B.ev_b_count.p, B.ev_b_step.p, B.live.p, B.frag_ps.p, B.frag_planes.p, B.frag_player.p,
+                   B.ev_b_count.p, B.ev_b_step.p, B.live.p, B.gseg.p, B.frag_ps.p, B.frag_planes.p, B.frag_player.p,
                    B.frag_cap, B.counters.p};
     const Tree T = tree_view(B);
     const Slots S = slots_view(*this, B);
+    const Segs G = segs_view(B, n_batches);
     const uint32_t quirks = (flags & DIEE_FLAG_REF_QUIRKS) ? 1u : 0u;
-    const PlayParams PP{seed, first_game_id, cfg->round_limit, (float)(1.0 / (double)temperature), quirks};
+    const PlayParams PP{cfg->round_limit, (float)(1.0 / (double)temperature), quirks};
 
-    HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
+    upload_segments(*this, bt);
     nn_reset_timing(*this);
-    launch_init_games(stream, Gm, n_games, first_game_id, seed);
+    launch_init_games(stream, Gm, G, n_games);
+    draw_noise(B, 0, bt, 0, cfg->dir_alpha);
     sync();
     // ---- timed region: every input is resident in HBM ----
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t n_live = n_games, step = 0;
+    std::vector<uint32_t> steps_of(n_batches, 0);                       // move-steps each batch took part in
+    std::vector<uint32_t> live_of(n_batches);
+    for (uint32_t k = 0; k < n_batches; ++k) live_of[k] = bt[k].n_games;
     const bool trace_steps = getenv("DIEE_TRACE_STEPS") != nullptr;      // development: batch size of every move-step
     while (n_live > 0 && (max_steps == 0 || step < max_steps)) {       // alpha_parallel.rs:129
         if (trace_steps) fprintf(stderr, "[diee] move-step %u: %u games alive\n", step, n_live);
-        launch_gather_roots(stream, Gm, S, n_live, first_game_id);
-        mcts_run(*this, n_live, *cfg, seed, step, flags);               // :146
-        launch_play_move(stream, T, Gm, n_live, step, PP);              // :164-224
-        launch_compact_live(stream, Gm, n_live, B.n_live_dev.p);        // :226-228
+        for (uint32_t k = 0; k < n_batches; ++k) if (live_of[k]) steps_of[k] = step + 1;
+        const int buf = (int)(step & 1u);
+        HIPCHK(hipMemsetAsync(B.seg_slots.p, 0, sizeof(uint32_t) * 2 * kMaxSegments, stream));
+        launch_gather_roots(stream, Gm, S, G, n_live);
+        HIPCHK(hipMemcpyAsync(B.counters_bak.p, B.counters.p, sizeof(unsigned long long) * CNT_COUNT * n_batches, hipMemcpyDeviceToDevice, stream));
+        mcts_run(*this, n_live, n_batches, *cfg, buf, flags);           // :146
+        // while the GPU searches: the next move-step's Dirichlet samples (the only host arithmetic of a move-step)
+        draw_noise(B, buf ^ 1, bt, step + 1, cfg->dir_alpha);
+        if (cluster_starved(*this)) {                                   // rare: repeat this move-step's search, per-layer kernels
+            HIPCHK(hipMemcpyAsync(B.counters.p, B.counters_bak.p, sizeof(unsigned long long) * CNT_COUNT * n_batches, hipMemcpyDeviceToDevice, stream));
+            mcts_run(*this, n_live, n_batches, *cfg, buf, flags);
+        }
+        launch_play_move(stream, T, Gm, G, n_live, step, PP);           // :164-224
+        launch_compact_live(stream, Gm, n_live, n_batches, B.n_live_dev.p);   // :226-228
         HIPCHK(hipGetLastError());
-        d2h(&n_live, B.n_live_dev.p, 1);
+        d2h(B.live_host, B.n_live_dev.p, (size_t)1 + n_batches);
         sync();
+        n_live = B.live_host[0];
+        for (uint32_t k = 0; k < n_batches; ++k) live_of[k] = B.live_host[1 + k];
         ++step;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     check_overflow();
-    nn_harvest(*this, stats);
     if (stats) {
-        read_counters(*this, stats);
-        stats->move_steps = step; stats->seconds = secs;
+        nn_harvest(*this, &stats[0]);                                   // sampled tower timings: whole call, reported with batch 0
+        for (uint32_t k = 0; k < n_batches; ++k) {
+            read_counters(*this, k, &stats[k]);
+            stats[k].move_steps = steps_of[k]; stats[k].seconds = secs;
+        }
+    } else {
+        nn_harvest(*this, nullptr);
     }
 
-    // ---- outputs: order = (move-step of the flush, game), round-limit flush before win flush ----
+    // ---- outputs, per batch: order = (move-step of the flush, game), round-limit flush before win flush ----
     std::vector<uint32_t> nfr(n_games), ea(n_games), eas(n_games), eb(n_games), ebs(n_games);
     std::vector<int8_t> win(n_games);
     d2h(nfr.data(), B.nfrags.p, (size_t)n_games); d2h(ea.data(), B.ev_a_count.p, (size_t)n_games);
@@ -256,52 +382,59 @@ void Engine::self_play(uint32_t n_games, uint32_t first_game_id, const diee_mcts
     d2h(ebs.data(), B.ev_b_step.p, (size_t)n_games); d2h(win.data(), B.winner.p, (size_t)n_games);
     sync();
     struct Ev { uint32_t step, g, kind, count; };
-    std::vector<Ev> evs;
-    size_t total = 0;
-    for (uint32_t g = 0; g < n_games; ++g) {
-        if (ea[g] != 0xFFFFFFFFu) { evs.push_back({eas[g], g, 0, ea[g]}); total += ea[g]; }
-        if (eb[g] != 0xFFFFFFFFu) { evs.push_back({ebs[g], g, 1, eb[g]}); total += eb[g]; }
-    }
-    std::sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) {
-        if (a.step != b.step) return a.step < b.step;
-        if (a.g != b.g) return a.g < b.g;
-        return a.kind < b.kind;
-    });
-    if (stats) stats->fragments = total;
-    if (!out || total == 0) return;
-    std::vector<int8_t> players((size_t)n_games * B.frag_cap);
-    d2h(players.data(), B.frag_player.p, players.size());
-    sync();
-    std::vector<uint32_t> src(total);
-    out->outcome = (int8_t*)malloc(total);
-    out->ps = (float*)malloc(total * 1352 * sizeof(float));
-    out->state = (float*)malloc(total * 144 * sizeof(float));
-    out->game = (uint32_t*)malloc(total * sizeof(uint32_t));
-    if (!out->outcome || !out->ps || !out->state || !out->game) {
-        free(out->outcome); free(out->ps); free(out->state); free(out->game); memset(out, 0, sizeof *out);
-        throw std::bad_alloc();
-    }
-    size_t k = 0;
-    for (const Ev& ev : evs)
-        for (uint32_t r = 0; r < ev.count; ++r, ++k) {
-            const size_t si = (size_t)ev.g * B.frag_cap + r;
-            src[k] = (uint32_t)si;
-            const int pl = players[si];
-            out->outcome[k] = ev.kind == 0 ? 0 : (win[ev.g] == pl ? 1 : (win[ev.g] == -pl ? -1 : 0));   // :216-217
-            out->game[k] = first_game_id + ev.g;
+    std::vector<int8_t> players;
+    for (uint32_t k = 0; k < n_batches; ++k) {
+        std::vector<Ev> evs;
+        size_t total = 0;
+        for (uint32_t g = game0[k]; g < game0[k] + bt[k].n_games; ++g) {
+            if (ea[g] != 0xFFFFFFFFu) { evs.push_back({eas[g], g, 0, ea[g]}); total += ea[g]; }
+            if (eb[g] != 0xFFFFFFFFu) { evs.push_back({ebs[g], g, 1, eb[g]}); total += eb[g]; }
         }
-    out->n = (uint32_t)total;
-    // gather on the device in chunks, then copy out
-    const size_t chunk = 65536;
-    B.out_src.ensure(chunk); B.out_ps.ensure(chunk * 1352); B.out_planes.ensure(chunk * 144);
-    for (size_t o = 0; o < total; o += chunk) {
-        const size_t m = std::min(chunk, total - o);
-        h2d(B.out_src.p, src.data() + o, m);
-        launch_gather_frags(stream, Gm, B.out_src.p, (uint32_t)m, B.out_ps.p, B.out_planes.p);
-        HIPCHK(hipGetLastError());
-        d2h(out->ps + o * 1352, B.out_ps.p, m * 1352);
-        d2h(out->state + o * 144, B.out_planes.p, m * 144);
-        sync();
+        std::sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) {
+            if (a.step != b.step) return a.step < b.step;
+            if (a.g != b.g) return a.g < b.g;
+            return a.kind < b.kind;
+        });
+        if (stats) stats[k].fragments = total;
+        if (!outs || total == 0) continue;
+        if (players.empty()) {
+            players.resize((size_t)n_games * B.frag_cap);
+            d2h(players.data(), B.frag_player.p, players.size());
+            sync();
+        }
+        std::vector<uint32_t> src(total);
+        FragBufs fb;
+        if (!fb.alloc(total)) {
+            for (uint32_t j = 0; j < k; ++j) diee_free_fragments(&outs[j]);
+            throw std::bad_alloc();
+        }
+        size_t q = 0;
+        for (const Ev& ev : evs)
+            for (uint32_t r = 0; r < ev.count; ++r, ++q) {
+                const size_t si = (size_t)ev.g * B.frag_cap + r;
+                src[q] = (uint32_t)si;
+                const int pl = players[si];
+                fb.outcome[q] = ev.kind == 0 ? 0 : (win[ev.g] == pl ? 1 : (win[ev.g] == -pl ? -1 : 0));   // :216-217
+                fb.game[q] = bt[k].first_game_id + (ev.g - game0[k]);
+            }
+        // gather on the device in chunks, then copy out
+        const size_t chunk = 65536;
+        B.out_src.ensure(chunk); B.out_ps.ensure(chunk * 1352); B.out_planes.ensure(chunk * 144);
+        try {
+            for (size_t o = 0; o < total; o += chunk) {
+                const size_t m = std::min(chunk, total - o);
+                h2d(B.out_src.p, src.data() + o, m);
+                launch_gather_frags(stream, Gm, B.out_src.p, (uint32_t)m, B.out_ps.p, B.out_planes.p);
+                HIPCHK(hipGetLastError());
+                d2h(fb.ps + o * 1352, B.out_ps.p, m * 1352);
+                d2h(fb.state + o * 144, B.out_planes.p, m * 144);
+                sync();
+            }
+        } catch (...) {
+            for (uint32_t j = 0; j < k; ++j) diee_free_fragments(&outs[j]);
+            throw;
+        }
+        fb.release(&outs[k], (uint32_t)total);
     }
 }
 

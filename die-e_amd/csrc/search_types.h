@@ -4,7 +4,12 @@
 //            are SoA so that a wave reading the children of a node issues coalesced 4-byte loads;
 //            children of a node are contiguous (first_child, n_children).
 //   Slots  : per-slot search state of one move-step (slot = index into the live list).
-//   Games  : per-game state of a self-play batch (game = index in the batch).
+//   Games  : per-game state of the self-play batches in flight (game = index over all batches, batch-major).
+//   Segs   : the self-play batches ("segments") that share the slot space.  A batch is one call of the reference's
+//            self_play_parallel: its games are coupled through the shared Dirichlet draw of a move-step, the
+//            `node_selected` flag of an iteration and the stale-slot quirk (Q14), and through nothing else -- so K
+//            batches can run side by side in ONE slot space (live games of batch 0, then of batch 1, ...) and share
+//            every network launch, each with its own seed, flags and slot-0 bookkeeping.
 #pragma once
 #include <stdint.h>
 
@@ -16,6 +21,7 @@ enum Counter {
     CNT_NN_EVALS = 0, CNT_EXPANSIONS, CNT_CHILDREN, CNT_TERMINAL, CNT_DEPTH_SUM, CNT_SELECTIONS,
     CNT_ILLEGAL, CNT_MAX_CHILDREN, CNT_PLIES, CNT_GAMES, CNT_COUNT
 };
+constexpr uint32_t kMaxSegments = 64;
 
 enum SlotCounter { SC_SELECTIONS = 0, SC_DEPTH_SUM, SC_TERMINAL, SC_EXPANSIONS, SC_CHILDREN, SC_MAX_CHILDREN, SC_ILLEGAL, SC_COUNT };
 
@@ -31,11 +37,22 @@ struct Tree {
     uint32_t node_cap;      // nodes per slot
 };
 
+struct Segs {
+    const unsigned long long* seed;   // [segs] engine seed of the batch (keys dice, sampling, Dirichlet)
+    const uint32_t* first_id;         // [segs] RNG key of the batch's game 0 (first_game_id)
+    const uint32_t* game0;            // [segs] index of the batch's game 0 in the Games arrays
+    uint32_t* first_slot;             // [segs] first live slot of the batch this move-step ...
+    uint32_t* end_slot;               // [segs] ... and one past its last (both 0: no live game)
+    uint32_t n;                       // batches in flight
+    uint32_t iter_cap;                // iterations per batch in Slots::iter_flags
+};
+
 struct Slots {
     BgState* roots;         // [slots]
     BgState* eval_states;   // [slots] states evaluated by the ResNet this iteration (stale rows keep their content)
     uint32_t* game_id;      // [slots] RNG key
     uint32_t* round;        // [slots] RNG key
+    uint32_t* seg;          // [slots] batch the slot's game belongs to
     uint32_t* leaf;         // [slots] selected leaf this iteration
     uint32_t* sel;          // [slots] selected_nodes_idxs (persists over iterations; 0xFFFFFFFF = initial)
     float* sel_value;       // [slots] NN value of sel
@@ -43,10 +60,10 @@ struct Slots {
     const float* logits;    // [slots][1352] policy logits of this iteration's evaluation (nn_host's buffers)
     const float* hv;        // [slots][72] value features
     const float* wv;        // [73] value FC
-    float* noise;           // [1352] Dirichlet sample of this move-step
-    float* root_value0;     // [1] NN value of slot 0's root
-    uint32_t* iter_flags;   // [2*(iterations)] any_selected, stale-initial count per iteration
-    unsigned long long* counters;  // [CNT_COUNT] totals (written by k_reduce_counters / single lanes only)
+    float* noise;           // [segs][1352] Dirichlet sample of this move-step, one per batch (noise.rs:27-34)
+    float* root_value0;     // [segs] NN value of the root in the batch's first slot
+    uint32_t* iter_flags;   // [segs][iter_cap][2] any_selected, stale-initial count per iteration
+    unsigned long long* counters;  // [segs][CNT_COUNT] totals (written by k_reduce_counters / single lanes only)
     uint32_t* slot_cnt;     // [slots][SC_COUNT] per-slot counters of this move-step: same-address atomics from a
                             // thousand waves serialise at ~11 ns each, per-slot words cost nothing
     uint32_t* overflow;     // capacity flag (bit0 sequence table, bit1 tree arena)
@@ -62,7 +79,8 @@ struct Games {
     uint32_t* ev_a_step;
     uint32_t* ev_b_count;   // win flush
     uint32_t* ev_b_step;
-    uint32_t* live;         // [games] live list (ascending game index)
+    uint32_t* live;         // [games] live list (ascending game index, hence batch-major)
+    uint8_t* seg;           // [games] batch of the game
     float* frag_ps;         // [games][frag_cap][1352]
     float* frag_planes;     // [games][frag_cap][144]
     int8_t* frag_player;    // [games][frag_cap]
@@ -71,14 +89,11 @@ struct Games {
 };
 
 struct SearchParams {
-    uint64_t seed;
     float dir_eps;
     uint32_t quirks;
 };
 
 struct PlayParams {
-    uint64_t seed;
-    uint32_t first_id;
     uint32_t round_limit;
     float inv_temperature;
     uint32_t quirks;

@@ -70,6 +70,10 @@ typedef struct {
 #define DIEE_FLAG_REF_QUIRKS 1u /* reproduce SURVEY Appendix A Q14 (stale selected_nodes_idxs
                                    slots, alpha_mcts.rs:142,157-166,175-200) and Q18 (double
                                    flush, alpha_parallel.rs:172-180,215-223)                */
+#define DIEE_FLAG_INVARIANT_NN 2u /* evaluate every batch size with the fused 16x16x32 tower (one arithmetic
+                                   for all sizes): the network output of a state is then a pure function of
+                                   the state, whatever shares its launch.  Slower below 257 boards (the
+                                   default picks a latency-optimised split-K kernel there).        */
 
 typedef struct {
     uint64_t games;            /* games retired (winner or round limit)                    */
@@ -128,6 +132,10 @@ size_t      diee_weights_count(int game_id);
 diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t n);
 diee_status diee_load_weights(diee_ctx*, const float* blob, size_t n);
 
+/* batch-size independent network arithmetic for every later call on this ctx (what DIEE_FLAG_INVARIANT_NN
+ * selects for one call): see the flag.  Needs loaded weights. */
+diee_status diee_set_invariant_nn(diee_ctx*, int on);
+
 /* ---- ResNet::forward_t, nnet.rs:120-133 (eval mode): softmax policy [n][1352], tanh value [n] */
 diee_status diee_nn_forward(diee_ctx*, const diee_bg_state* states, uint32_t n,
                             float* policy, float* value);
@@ -151,6 +159,25 @@ diee_status diee_self_play(diee_ctx*, uint32_t n_games, uint32_t first_game_id,
                            diee_fragments* out /* may be NULL: keep results in HBM only */,
                            diee_stats* stats);
 void        diee_free_fragments(diee_fragments*);
+
+/* ---- level 2, pipelined: n_batches calls of self_play_parallel played side by side on one GPU.
+ * learn_parallel issues self_play_iterations such calls back to back with the same network
+ * (alpha_parallel.rs:49-62); a single batch ends in a long tail of move-steps with a handful of live
+ * games, during which the GPU idles.  Here every batch starts at move-step 0 and all of them share each
+ * network launch; each keeps its own seed, game ids, Dirichlet stream, `node_selected` flags and slot-0
+ * bookkeeping (Q14), so batch b produces what diee_self_play(batches[b]) produces -- byte for byte when the
+ * ResNet kernel is batch-size independent (DIEE_FLAG_INVARIANT_NN), otherwise up to which bf16 tower
+ * kernel evaluated a row (the dispatch goes by the number of live games; all are within the NN tolerance).
+ * outs / stats: [n_batches] (either may be NULL); stats[b].seconds is the wall clock of the whole call,
+ * the sampled tower timings are reported with batch 0. */
+typedef struct {
+    uint32_t n_games;          /* num_self_play_batches of this call                        */
+    uint32_t first_game_id;    /* offsets the RNG keys, as in diee_self_play                 */
+    uint64_t seed;
+} diee_batch;
+diee_status diee_self_play_multi(diee_ctx*, const diee_batch* batches, uint32_t n_batches,
+                                 const diee_mcts_cfg* cfg, float temperature, uint32_t flags,
+                                 uint32_t max_steps, diee_fragments* outs, diee_stats* stats);
 
 /* ---- pure game functions, batched on the GPU (parity tests; LearnableGame trait, base.rs:8-51)
  * A play is int8 {f1,t1,f2,t2}; unused slots DIEE_NO_MOVE. */

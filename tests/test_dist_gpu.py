@@ -1,0 +1,38 @@
+"""The multi-rank code path of bench.py on hardware: launched exactly as the driver launches it for N > 1
+(python -m torch.distributed.run ... bench.py --gpus N), here with ONE rank on the one GPU of the box.  RCCL
+initialises, torch's HIP runtime and libdiee.so's share the process, barrier + MAX / SUM reductions run on the GPU.
+The launcher is a FRESH child process (it starts before anything touches the GPU; nothing is re-exec'ed)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()[-3000:]
+
+
+def test_bench_under_torch_distributed_run_world_size_1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--gpus", "1", "--steps", "1", "--max-steps", "2", "--no-cpu-baseline", "--games", "256", "--pipeline", "0"]
+    port = str(29400 + os.getpid() % 500)
+    rc, dist_line, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                               "--master-addr", "127.0.0.1", "--master-port", port, "bench.py"] + args, env)
+    assert rc == 0, err
+    assert dist_line is not None, err
+    assert dist_line["n_gpus"] == 1 and dist_line["scaling"] == "weak" and dist_line["node_expansions_per_s"] > 0
+    rc2, plain, err2 = _run([sys.executable, "bench.py"] + args, env)
+    assert rc2 == 0 and plain is not None, err2
+    # same seeds, same shard (rank 0): the counters of the distributed run equal the plain run's
+    for key in ("games", "move_steps", "fragments", "illegal_decodes"):
+        assert dist_line["stats"][key] == plain["stats"][key], key
+    assert abs(dist_line["stats"]["expansions_per_game"] - plain["stats"]["expansions_per_game"]) < 1e-9
+    assert dist_line["config"]["parallelism"].startswith("dp1")

@@ -143,3 +143,77 @@ def test_self_play_plays_to_completion(eng, oracle):
     for g in range(n):
         m = out["game"] == g
         assert (out["outcome"][m] * pl[m, 0] == (out["outcome"][m] * pl[m, 0])[0]).all()
+
+
+# ---- pipelined self-play: K batches side by side, merged network launches -------------------------------------------
+def _cmp_batch(m, ref, n, check_steps=True):
+    if check_steps:
+        assert m["stats"]["move_steps"] == ref["steps"]
+    assert len(m["outcome"]) == len(ref["outcome"]) > 0
+    assert (m["game"] == ref["game"]).all() and (m["outcome"] == ref["outcome"]).all()
+    assert m["state"].tobytes() == ref["state"].tobytes()
+    assert m["ps"].tobytes() == ref["ps"].tobytes()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert m["stats"][key] == ref["stats"][key], key
+    assert m["stats"]["games"] == n and m["stats"]["illegal_decodes"] == 0
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_self_play_multi_bit_exact_vs_lockstep_oracle(eng, oracle, quirks):
+    """diee_self_play_multi against the oracle's restatement of K self_play_parallel calls in lockstep with ONE merged
+    evaluator call per search phase (same row order: live games of batch 0, then 1, ...): records, policy targets,
+    outcomes, per-batch counters and per-batch lengths identical"""
+    ocfg, gcfg = cfgs(oracle, 10, round_limit=50)
+    batches = [(10, 0, SEED), (6, 50, SEED + 1), (1, 7, SEED + 2), (12, 200, SEED)]
+    ev, calls = gpu_eval(eng, oracle)
+    ref, total = oracle.self_play_multi(1, batches, ocfg, 1.25, ev, None, ref_quirks=quirks)
+    out = eng.self_play_multi(batches, gcfg, 1.25, ref_quirks=bool(quirks))
+    assert max(o["stats"]["move_steps"] for o in out) == total
+    for (n, first, seed), m, r in zip(batches, out, ref):
+        _cmp_batch(m, r, n)
+        assert set(np.unique(m["game"])) <= set(range(first, first + n))
+
+
+def test_self_play_multi_equals_sequential_calls_when_the_network_is_batch_invariant(eng, oracle):
+    """with DIEE_FLAG_INVARIANT_NN every batch size runs the fused 16x16x32 tower, the network output of a state no
+    longer depends on what shares its launch, and K batches played side by side produce EXACTLY what K sequential
+    diee_self_play calls produce -- at sizes where the default dispatch would switch kernels (130 + 140 games merged =
+    fused tower, alone = cluster tower) -- and exactly what K oracle runs produce"""
+    _, gcfg = cfgs(oracle, 3, round_limit=6)
+    ocfg, _ = cfgs(oracle, 3, round_limit=6)
+    batches = [(130, 0, SEED + 5), (140, 1000, SEED + 6), (9, 5000, SEED + 7)]
+    multi = eng.self_play_multi(batches, gcfg, 1.25, ref_quirks=True, invariant_nn=True)
+    eng.set_invariant_nn(True)
+    try:
+        ev, _ = gpu_eval(eng, oracle)
+        for (n, first, seed), m in zip(batches, multi):
+            single = eng.self_play_parallel(n, gcfg, 1.25, seed, ref_quirks=True, first_game_id=first, invariant_nn=True)
+            for key in ("outcome", "game"):
+                assert (m[key] == single[key]).all()
+            assert m["ps"].tobytes() == single["ps"].tobytes() and m["state"].tobytes() == single["state"].tobytes()
+            for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "move_steps", "plies"):
+                assert m["stats"][key] == single["stats"][key], key
+            if n <= 9:      # and the oracle, run on its own with the same (now pure) evaluator
+                ref = oracle.self_play_parallel(1, n, ocfg, 1.25, seed, ev, None, ref_quirks=1, first_game_id=first)
+                _cmp_batch(m, ref, n)
+    finally:
+        eng.set_invariant_nn(False)
+
+
+def test_mcts_batch_bit_exact_above_one_chip_pass(eng, oracle):
+    """more roots than one pass of the chip through the 4-board fused tower (1024): whole passes in one launch, the
+    remainder (here 1100 - 1024 = 76 boards: cluster tower) in a launch of its own; the search stays bit-exact against
+    the oracle, whose evaluator calls go through the same split"""
+    n = 1100
+    walk = oracle.random_walk_states(123, 40)
+    states = walk[10:10 + 3 * n:3]
+    assert len(states) == n
+    ocfg, gcfg = cfgs(oracle, 3)
+    ev, _ = gpu_eval(eng, oracle)
+    gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 3
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, ev, None, SEED, 2, gids, rds, 1)
+    r = eng.alpha_mcts_parallel(states, gcfg, SEED, 2, gids, rds, ref_quirks=True)
+    assert r["probs"].tobytes() == probs.tobytes()
+    gs, os_ = r["stats"], ostats.as_dict()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert gs[key] == os_[key], (key, gs[key], os_[key])
