@@ -27,9 +27,18 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_
 FLOPS_PER_EVAL = 1_082_450_064
 
 
-def cpu_baseline(n_games, iterations, max_steps, seed, exp_per_game):
-    """the CPU oracle (C restatement of the reference's serial tree loops) + PyTorch fp32 CPU ResNet
-    (what tch/libtorch gives the reference on a CPU-only host), on a bounded sample"""
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64):
+    """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
+    ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
+    `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike).
+
+      B-ref  as die-e runs self-play today: ONE batched search over all roots, tree loops on one thread
+             (alpha_mcts.rs:153-168,192-200), the network batch on every core (libtorch intra-op pool);
+      B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308): one search per root,
+             one root per host thread, batch-1 network evaluations on that thread -- no cross-game batching, no
+             serial section.
+    Returns the faster of the two as `value` (games/s, extrapolated with the GPU run's expansions per game)."""
+    import concurrent.futures as cf
     import numpy as np
     import torch
     import diee_amd
@@ -37,25 +46,55 @@ def cpu_baseline(n_games, iterations, max_steps, seed, exp_per_game):
     from oracle import nn_ref
     orc.build()
     net = nn_ref.parse(diee_amd.random_weights(0))
-    cores = torch.get_num_threads()
+    cores = os.cpu_count() or 1
+    walk = orc.random_walk_states(seed & 0xFFFF, 40)
+    roots = walk[np.linspace(3, len(walk) - 1, n_roots).astype(int)]
+    cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
 
     def fn(states_u8):
         st = states_u8.view(orc.BG_STATE).reshape(-1)
         pol, val, _ = nn_ref.forward_t(net, orc.planes_batch(st))
         return pol, val
-    ev = orc.make_eval(fn, 1352)
-    cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+
+    def search(states, first_id):
+        ev = orc.make_eval(fn, 1352)
+        n = len(states)
+        _, _, st, _ = orc.alpha_mcts_parallel(1, states, cfg, ev, None, seed, 0, np.arange(first_id, first_id + n, dtype=np.uint32),
+                                              np.zeros(n, dtype=np.uint32), 1)
+        return st.as_dict()
+
+    out = {"unit": "games/s", "kind": "port", "cores": cores, "variants": {}}
+    # B-ref
+    torch.set_num_threads(cores)
+    t = time.time(); st = search(roots, 0); dt = time.time() - t
+    out["variants"]["B-ref"] = {
+        "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores,
+        "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
+        "what": f"one batched search over {n_roots} roots (serial C tree loops + fp32 PyTorch CPU ResNet on {cores} intra-op threads)"}
+    # B-omp
+    torch.set_num_threads(1)
+    workers = max(1, min(cores, n_roots))
     t = time.time()
-    r = orc.self_play_parallel(1, n_games, cfg, 1.25, seed, ev, None, ref_quirks=1, max_steps=max_steps)
+    with cf.ThreadPoolExecutor(workers) as ex:
+        sts = list(ex.map(lambda i: search(roots[i:i + 1], i), range(n_roots)))
     dt = time.time() - t
-    exps = r["stats"]["expansions"]
-    return {
-        "value": (exps / dt) / exp_per_game if exp_per_game else None, "unit": "games/s",
-        "expansions_per_s": exps / dt, "cores": cores, "kind": "port",
-        "sample": f"oracle (single-threaded C tree/game logic) + PyTorch fp32 CPU ResNet ({cores} intra-op threads): "
-                  f"{n_games} games x {max_steps} move-steps, iterations={iterations}, {exps} expansions in {dt:.1f} s; "
-                  f"games/s extrapolated with the GPU run's {exp_per_game:.0f} expansions per game",
-    }
+    exps = sum(s["expansions"] for s in sts)
+    out["variants"]["B-omp"] = {
+        "expansions_per_s": exps / dt, "seconds": dt, "threads": workers,
+        "mean_children": sum(s["children"] for s in sts) / max(exps, 1),
+        "mean_leaf_depth": sum(s["depth_sum"] for s in sts) / max(sum(s["selections"] for s in sts), 1),
+        "what": f"{n_roots} independent searches, one per host thread ({workers} threads), batch-1 fp32 evaluations on that thread"}
+    torch.set_num_threads(cores)
+    best = max(out["variants"], key=lambda k: out["variants"][k]["expansions_per_s"])
+    eps = out["variants"][best]["expansions_per_s"]
+    out["expansions_per_s"] = eps
+    out["value"] = eps / exp_per_game if exp_per_game else None
+    out["cores"] = out["variants"][best]["threads"]
+    out["sample"] = (f"{best} (the faster of B-ref / B-omp, both in `variants`): oracle (C restatement of the reference's tree / game "
+                     f"loops) + PyTorch fp32 CPU ResNet, one move-step of search (iterations={iterations}) on {n_roots} positions "
+                     f"drawn evenly from random self-play walks (opening to bear-off); games/s extrapolated with the GPU run's "
+                     f"{exp_per_game:.0f} expansions per game")
+    return out
 
 
 def main():
@@ -217,7 +256,7 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(8, args.iterations, 2, args.seed, exp_per_game)
+                out["cpu_baseline"] = cpu_baseline(args.iterations, args.seed, exp_per_game)
             except Exception as e:                   # the baseline is a report, never a reason to lose the line
                 out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

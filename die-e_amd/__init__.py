@@ -36,14 +36,16 @@ BG_STATE = np.dtype([("pts", "i1", 24), ("bar", "u1", 2), ("off", "u1", 2), ("ro
                      ("player", "i1"), ("second", "u1")])
 assert BG_STATE.itemsize == 32
 
-# every symbol include/diee.h declares (checked by the CPU test-suite against the built library)
+# every symbol include/diee.h declares (checked by the CPU test-suite against the built library); the development probes
+# of include/diee_dev.h are listed in DEV_EXPORTS
 EXPORTS = [
     "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
     "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
     "diee_self_play_multi", "diee_set_invariant_nn",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
-    "diee_bg_planes", "diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench",
+    "diee_bg_planes", "diee_det_pow",
 ]
+DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench"]
 
 
 class DieeError(RuntimeError):
@@ -126,6 +128,7 @@ def load_library(path=None):
     L.diee_bg_decode.argtypes = [vp, vp, vp, u32, vp]; L.diee_bg_decode.restype = C.c_int
     L.diee_bg_apply.argtypes = [vp, vp, vp, vp, u32]; L.diee_bg_apply.restype = C.c_int
     L.diee_bg_planes.argtypes = [vp, vp, u32, vp]; L.diee_bg_planes.restype = C.c_int
+    L.diee_det_pow.argtypes = [vp, vp, vp, u32, vp]; L.diee_det_pow.restype = C.c_int
     L.diee_probe_f32.argtypes = [vp, vp, vp, u32, vp, vp, vp]; L.diee_probe_f32.restype = C.c_int
     L.diee_probe_dice.argtypes = [vp, u64, vp, u32, vp, vp]; L.diee_probe_dice.restype = C.c_int
     L.diee_dev_conv_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]; L.diee_dev_conv_bench.restype = C.c_int
@@ -222,6 +225,14 @@ class Engine:
         s = _states(states); n = len(s)
         out = np.zeros((n, BG_PLANES), dtype=np.float32)
         self._chk(self._L.diee_bg_planes(self._h, s.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def det_pow(self, x, y):
+        """Tensor::pow_ of the drivers (alpha_parallel.rs:165, versus.rs:283) with the engine's deterministic powf"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(np.broadcast_to(np.asarray(y, dtype=np.float32), x.shape))
+        out = np.zeros_like(x)
+        self._chk(self._L.diee_det_pow(self._h, x.ctypes.data, y.ctypes.data, x.size, out.ctypes.data))
         return out
 
     def probe_f32(self, a, b):

@@ -5,7 +5,8 @@ play_vs_best_model} (src/alphazero/alphazero.rs, alpha_parallel.rs, alpha_versus
 Self-play and model-vs-model search run on the HIP engine through the C ABI.  The training step is
 PyTorch-ROCm (the reference's is tch/libtorch autograd; SURVEY: "do it in PyTorch-ROCm, not
 hand-written backward"), data-parallel over ranks with DistributedDataParallel on RCCL.  Tensors are
-stored as .npy instead of libtorch .ot archives (F3: a converter, not a native reader, is the plan).
+stored as .npy; libtorch .ot archives (models and training data) are read wherever a path is given and
+written on request (die-e_amd/ot.py, scripts/ot_convert.py: F3).
 """
 import os
 import secrets
@@ -15,6 +16,7 @@ import numpy as np
 import torch
 
 from . import BG_ACTIONS, BG_PLANES, Engine, MctsConfig, random_weights
+from . import ot as _ot
 
 # PyTorch bundles its own HIP runtime; it has to initialise BEFORE libdiee.so's (system ROCm) runtime does,
 # otherwise torch.cuda reports no device.  Importing this module first (the CLI and the learn loop do) is enough.
@@ -146,6 +148,7 @@ class AlphaZero:
         self.rank, self.world, self.root, self.quiet = rank, world, root, quiet
         self.seed = seed
         self.calls = 0
+        self.shuffle_rng = np.random.default_rng(seed ^ 0x5EED)     # memory.shuffle(&mut thread_rng()) once per train() call, alphazero.rs:203-204
         self.blob = np.ascontiguousarray(blob if blob is not None else random_weights(0), dtype=np.float32)
         if engine is not None:
             engine.load_weights(self.blob)
@@ -154,7 +157,9 @@ class AlphaZero:
         self.ddp = None
         if world > 1:
             from torch.nn.parallel import DistributedDataParallel as DDP
-            self.ddp = DDP(self.model, device_ids=[torch.cuda.current_device()] if self.device == "cuda" else None)
+            dev = torch.device(self.device)
+            self.ddp = DDP(self.model, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()]
+                           if dev.type == "cuda" else None)
         # Adam::default().wd(op.wd).build(&vs, op.lr), alphazero.rs:102 (L2 added to the gradient, not AdamW)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=op.lr, betas=(0.9, 0.999), eps=1e-8,
                                           weight_decay=op.wd)
@@ -162,11 +167,12 @@ class AlphaZero:
     @classmethod
     def from_config(cls, engine, conf, model_path=None, **kw):                   # alphazero.rs:113-127, :81-100
         blob = None
-        best = os.path.join(kw.get("root", "."), "models", "backgammon", "best_model.npy")
+        mdir = os.path.join(kw.get("root", "."), "models", "backgammon")
+        best = next((p for p in (os.path.join(mdir, "best_model.npy"), os.path.join(mdir, "best_model.ot")) if os.path.exists(p)), None)
         if model_path:
-            blob = np.load(model_path)
-        elif os.path.exists(best):
-            blob = np.load(best)
+            blob = _ot.load_model(model_path)                                    # .npy blob or die-e's own .ot archive
+        elif best:
+            blob = _ot.load_model(best)
         return cls(engine, AlphaZeroConfig.from_config(conf), mcts_config_from(conf), OptimizerParams.from_config(conf),
                    blob=blob, **kw)
 
@@ -186,20 +192,29 @@ class AlphaZero:
 
     # ---- save/load_training_data, alphazero.rs:149-200 (ps [M,1352], states [M,6,4,6], outcomes [M] i8) ----
     @staticmethod
-    def save_training_data(memory, path):
+    def save_training_data(memory, path, fmt=None):
+        """fmt: "npy" (default), "ot" (the reference's ps.ot / states.ot / outcomes.ot) or "both"; DIEE_DATA_FORMAT overrides"""
         if not os.path.isdir(path):
             raise FileNotFoundError(f"path: {path} does not exist!")
-        np.save(os.path.join(path, "ps.npy"), memory["ps"])
-        np.save(os.path.join(path, "states.npy"), memory["state"].reshape(-1, 6, 4, 6))
-        np.save(os.path.join(path, "outcomes.npy"), memory["outcome"].astype(np.int8))
+        fmt = fmt or os.environ.get("DIEE_DATA_FORMAT", "npy")
+        arrays = {"ps": memory["ps"], "states": memory["state"].reshape(-1, 6, 4, 6), "outcomes": memory["outcome"].astype(np.int8)}
+        for stem, a in arrays.items():
+            if fmt in ("npy", "both"):
+                np.save(os.path.join(path, stem + ".npy"), a)
+            if fmt in ("ot", "both"):
+                _ot.save_tensor_ot(a, os.path.join(path, stem + ".ot"))
 
     @staticmethod
     def load_training_data(path):
         if not os.path.isdir(path):
             raise FileNotFoundError(f"path: {path} does not exist!")
-        return {"ps": np.load(os.path.join(path, "ps.npy")),
-                "state": np.load(os.path.join(path, "states.npy")).reshape(-1, BG_PLANES),
-                "outcome": np.load(os.path.join(path, "outcomes.npy"))}
+
+        def one(stem):
+            npy = os.path.join(path, stem + ".npy")
+            return np.load(npy) if os.path.exists(npy) else _ot.load_tensor_ot(os.path.join(path, stem + ".ot"))
+        return {"ps": one("ps").reshape(-1, BG_ACTIONS).astype(np.float32),
+                "state": one("states").reshape(-1, BG_PLANES).astype(np.float32),
+                "outcome": one("outcomes").reshape(-1).astype(np.int8)}
 
     @staticmethod
     def concat(mems):
@@ -214,13 +229,22 @@ class AlphaZero:
         import torch
         import torch.nn.functional as Fn
         n = len(memory["outcome"])
-        rng = rng or np.random.default_rng(self.seed + self.calls)
+        rng = rng or self.shuffle_rng                                           # a fresh permutation every call (every epoch)
         perm = rng.permutation(n)                                               # memory.shuffle(&mut rng), :203-204
         net = self.ddp or self.model
         net.train()                                                             # forward_train(.., true): BN batch statistics
         losses = []
         bs = self.config.training_batch_size
-        for b0 in range(0, n, bs):                                              # :205-206
+        n_steps = -(-n // bs)
+        if self.ddp is not None:
+            # ranks play different games, so their fragment counts differ: every rank must take the SAME number of
+            # all-reduced steps or the longest one waits in backward() forever.  All take the minimum; the ranks with
+            # more data leave their last permuted fragments out of this epoch (a fresh permutation comes next epoch).
+            import torch.distributed as dist
+            t = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_steps = int(t.item())
+        for b0 in range(0, n_steps * bs, bs):                                   # :205-206
             idx = perm[b0:b0 + bs]
             st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6).to(self.device)
             ps = torch.from_numpy(memory["ps"][idx]).to(self.device)
@@ -241,6 +265,14 @@ class AlphaZero:
         """fold the trained weights back into the HIP engine (BN running statistics included)"""
         self.model.eval()
         self.blob = self.model.to_blob()
+        if self.ddp is not None:
+            # parameters are identical on every rank (all-reduced gradients), BatchNorm running statistics are not
+            # (each rank saw its own batches): every engine gets rank 0's blob
+            import torch.distributed as dist
+            t = torch.from_numpy(self.blob).to(self.device)
+            dist.broadcast(t, src=0)
+            self.blob = t.cpu().numpy()
+            self.model.load_blob(self.blob)
         if not np.isfinite(self.blob).all():
             raise FloatingPointError("nan variables detected!")                 # alpha_parallel.rs:83
         if self.engine is not None:
@@ -289,6 +321,8 @@ class AlphaZero:
         from .versus import Agent, Player, play
         mdir = os.path.join(self.root, "models", "backgammon")
         best = os.path.join(mdir, "best_model.npy")
+        if not os.path.exists(best) and os.path.exists(os.path.join(mdir, "best_model.ot")):
+            np.save(best, _ot.load_model_ot(os.path.join(mdir, "best_model.ot")))   # a die-e checkpoint brought along
         if not os.path.exists(best):
             self.log("No best model was found, saving current model as best...")
             os.makedirs(mdir, exist_ok=True)

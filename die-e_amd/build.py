@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libdiee.so")
+OUT = os.path.join(HERE, os.environ.get("DIEE_OUT", "libdiee.so"))      # diagnostic builds: DIEE_OUT=libdiee_clock.so DIEE_EXTRA_FLAGS=-D...
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -22,17 +22,17 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "diee.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("diee.h", "diee_dev.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if os.path.basename(OUT) == "libdiee.so" else "build_" + os.path.basename(OUT))
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "diee.h")))
+    hdr_t = max([hdr_t] + [os.path.getmtime(os.path.join(HERE, "..", "include", h)) for h in ("diee.h", "diee_dev.h")])
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(objdir, src + ".o")

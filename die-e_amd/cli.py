@@ -75,6 +75,7 @@ def main(argv=None):
     from . import Engine
     from .alphazero import AlphaZero, load_config, mcts_config_from
     from .versus import Agent, EngineRules, Player, play, print_game, save_game
+    from .ot import load_model, save_model_ot
     if args.command == "replay":                                                              # main.rs:208-213
         print_game(args.game_path, wait_user_input=sys.stdin.isatty())
         return 0
@@ -84,10 +85,25 @@ def main(argv=None):
         sys.exit(f"Value provided in n_cpus flag ({args.n_cpus}) is larger than total cpus in the device ({n_cpus})!")
     print(f"Number of CPU's to use {args.n_cpus or n_cpus // 2}")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    eng = Engine(local_rank)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = local_rank
+    if world > 1:
+        # under torch.distributed.run: one rank per GPU.  torch picks its device and RCCL comes up BEFORE the engine
+        # touches the GPU (torch's HIP runtime has to initialise first; nothing is re-exec'ed afterwards)
+        import torch
+        import torch.distributed as dist
+        ndev = max(torch.cuda.device_count(), 1)
+        device = local_rank % ndev
+        if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+            os.environ["DIEE_TOWER_CL"] = "none"       # ranks share a GPU: no in-launch hand-overs between co-resident grids
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    eng = Engine(device)
     if args.command == "learn":                                                               # main.rs:121-124
-        az = AlphaZero.from_config(eng, conf, model_path=args.model_path, rank=int(os.environ.get("RANK", "0")),
-                                   world=int(os.environ.get("WORLD_SIZE", "1")))
+        az = AlphaZero.from_config(eng, conf, model_path=args.model_path, rank=rank, world=world,
+                                   train_device=(f"cuda:{device}" if world > 1 else None))
         for row in az.learn_parallel():
             print(row)
     elif args.command == "play":                                                              # main.rs:125-171
@@ -100,8 +116,8 @@ def main(argv=None):
         def model(path):
             if path is None:
                 return None
-            e = Engine(local_rank)
-            e.load_weights(np.load(path))
+            e = Engine(device)
+            e.load_weights(load_model(path))                                                  # .npy blob or die-e's .ot archive
             return e
         m1, m2 = model(args.model_path_one), model(args.model_path_two)
         res = play(Player(a1, m1), Player(a2, m2), mcts_config_from(conf), float(conf["temperature"]),
@@ -123,6 +139,9 @@ def main(argv=None):
         az.sync_engine()
         out = args.out_path or os.path.join(".", "models", "backgammon", "trained_model.npy")
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
-        np.save(out, az.blob)
+        if out.endswith(".ot"):
+            save_model_ot(az.blob, out)
+        else:
+            np.save(out, az.blob)
         print(f"Trained model saved successfully, saved to {out}")
     return 0

@@ -1,5 +1,6 @@
 // diee_api.cpp -- C ABI (include/diee.h) and host-side engine of libdiee.so.
 #include "../../include/diee.h"
+#include "../../include/diee_dev.h"
 #include "engine.h"
 #include "nn_host.h"
 
@@ -97,6 +98,13 @@ diee_status diee_bg_planes(diee_ctx* c, const diee_bg_state* s, uint32_t n, floa
     API_BEGIN(c)
     if (!s || !out) throw EngineError(DIEE_ERR_ARG, "null pointer");
     c->planes(s, n, out);
+    API_END(c)
+}
+
+diee_status diee_det_pow(diee_ctx* c, const float* x, const float* y, uint32_t n, float* out) {
+    API_BEGIN(c)
+    if (!x || !y || !out) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    c->probe_f32(x, y, n, nullptr, nullptr, out);
     API_END(c)
 }
 

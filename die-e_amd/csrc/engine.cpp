@@ -144,7 +144,9 @@ void Engine::probe_f32(const float* a, const float* b, uint32_t n, float* sq, fl
     h2d(tmp_a.p, (const uint8_t*)a, B); h2d(tmp_b.p, (const uint8_t*)b, B);
     launch_probe_f32(stream, (float*)tmp_a.p, (float*)tmp_b.p, n, (float*)tmp_c.p, (float*)tmp_d.p, (float*)tmp_e.p);
     HIPCHK(hipGetLastError());
-    d2h((uint8_t*)sq, tmp_c.p, B); d2h((uint8_t*)dv, tmp_d.p, B); d2h((uint8_t*)pw, tmp_e.p, B);
+    if (sq) d2h((uint8_t*)sq, tmp_c.p, B);
+    if (dv) d2h((uint8_t*)dv, tmp_d.p, B);
+    if (pw) d2h((uint8_t*)pw, tmp_e.p, B);
     sync();
 }
 

@@ -1001,22 +1001,25 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         *(u32x4*)(tl + ROWS * RS + (i % 36) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     uint32_t basep[9][(MF + 1) / 2];
+    auto fill_basep = [&](uint32_t (&bp)[9][(MF + 1) / 2], int ln) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int h = 0; h < (MF + 1) / 2; ++h) basep[t][h] = 0;
+            for (int h = 0; h < (MF + 1) / 2; ++h) bp[t][h] = 0;
 #pragma unroll
-    for (int f = 0; f < MF; ++f) {
-        const int R = tower_row<SP>(f, lane & 15);
-        const int p = R % 24, y = p / 6, x = p % 6;
+        for (int f = 0; f < MF; ++f) {
+            const int R = tower_row<SP>(f, ln & 15);
+            const int p = R % 24, y = p / 6, x = p % 6;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
-            const uint32_t ad = (uint32_t)((ok ? R + 6 * dy + dx : ROWS) * RS + (lane >> 4) * 16);
-            basep[t][f >> 1] |= (f & 1) ? ad << 16 : ad;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
+                const uint32_t ad = (uint32_t)((ok ? R + 6 * dy + dx : ROWS) * RS + (ln >> 4) * 16);
+                bp[t][f >> 1] |= (f & 1) ? ad << 16 : ad;
+            }
         }
-    }
+    };
+    fill_basep(basep, lane);
     __syncthreads();
     if (states) {
         // ---- init block: conv 6 -> 256 + BN + ReLU (nnet.rs:64-67), th -> tx, one 32-channel k-step per tap; in the
@@ -1075,6 +1078,15 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     if (whead) {
+        // Everything the head convs need per lane is derived again from an opaque copy of the thread id: left alone the
+        // compiler keeps the init block's unpacked tile addresses (and friends) alive across the 38 layers -- in scratch:
+        // 36 dwords per lane stored before the tower and reloaded here, the 18 MB of WRITE_SIZE per launch that round 1
+        // read as partial-line stores.
+        int htid = tid;
+        asm volatile("" : "+v"(htid));
+        const int lane = htid & 63, wave = __builtin_amdgcn_readfirstlane(htid >> 6);
+        uint32_t basep[9][(MF + 1) / 2];
+        fill_basep(basep, lane);
         // ---- head convs in here (nnet.rs:76-78, 88-90): policy 32 + value 3 channels = three 16-column fragments, each
         // over the whole K; with 8 waves the fragments of a column go to two waves (every other row fragment each).
         // The tower output never leaves the CU: no x_out store, no head-conv launch. ----
@@ -1118,28 +1130,37 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // The head features are staged in the idle tile `th` -- policy [row][32] bf16 (64 B rows), value [row][3] f32 --
+            // and leave the CU below as whole 16-byte-per-lane lines: a lane holds 4 channels of one position, stored
+            // straight to hp / hv that was an 8-byte partial-line write per lane (rocprofv3 WRITE_SIZE 20.3 MB per launch
+            // at 1024 boards for 1.87 MB of features, round 1).
             const int n0 = nt * 16 + (lane >> 4) * 4;
             const float4 bv = *(const float4*)(bhead + n0);
 #pragma unroll
             for (int j = 0; j < MFH; ++j) {
                 const int f = mh + HW * j;
                 if (f >= MF) continue;
-                const int r = tower_row<SP>(f, lane & 15), gr = row0 + r;
-                if ((ROWS % 16 != 0 && r >= ROWS) || gr >= M) continue;
+                const int r = tower_row<SP>(f, lane & 15);
+                if (ROWS % 16 != 0 && r >= ROWS) continue;
                 float v0 = acc[j][0] + bv.x, v1 = acc[j][1] + bv.y, v2 = acc[j][2] + bv.z, v3 = acc[j][3] + bv.w;
                 v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
-                const int g = gr / 24, p = gr % 24;
                 if (n0 < 32) {
                     uint2 o;
                     o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
                     o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                    *(uint2*)(hp + (size_t)g * 768 + p * 32 + n0) = o;
+                    *(uint2*)(th + r * 64 + n0 * 2) = o;
                 } else if (n0 == 32) {
-                    float* ov = hv + (size_t)g * 72 + p * 3;
+                    float* ov = (float*)(th + ROWS * 64) + r * 3;
                     ov[0] = v0; ov[1] = v1; ov[2] = v2;
                 }
             }
         }
+        __syncthreads();
+        // hp [g][p*32 + c] and hv [g][p*3 + c] of this workgroup's boards are contiguous in HBM: 16 bytes per lane
+        for (int i = tid; i < ROWS * 4; i += NT)
+            if (row0 + (i >> 2) < M) *(u32x4*)(hp + (size_t)row0 * 32 + i * 8) = *(const u32x4*)(th + i * 16);
+        for (int i = tid; i < ROWS * 3 / 4; i += NT)
+            if (row0 + (i * 4) / 3 < M) *(u32x4*)(hv + (size_t)row0 * 3 + i * 4) = *(const u32x4*)(th + ROWS * 64 + i * 16);
         return;
     }
     for (int i = tid; i < ROWS * 32; i += NT) {

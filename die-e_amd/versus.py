@@ -50,7 +50,7 @@ class EngineRules:
         return self.e.decode(states, codes)
 
     def powf(self, x, y):
-        return self.e.probe_f32(x, np.full_like(x, y))[2]
+        return self.e.det_pow(x, y)
 
     def draws(self, seed, ctr):
         return self.e.probe_dice(seed, ctr)     # (dice [n,2], uniform [n])

@@ -194,23 +194,10 @@ diee_status diee_bg_apply(diee_ctx*, diee_bg_state* s /* in/out */, const int8_t
                           const uint8_t* dice, uint32_t n);
 /* as_tensor, backgammon_logic.rs:198-252: out[n][144] */
 diee_status diee_bg_planes(diee_ctx*, const diee_bg_state* s, uint32_t n, float* out);
-/* device arithmetic probes for the bit-exactness tests (f32 sqrt/div, det_pow, Philox dice) */
-diee_status diee_probe_f32(diee_ctx*, const float* a, const float* b, uint32_t n,
-                           float* sqrt_a, float* a_div_b, float* pow_ab);
-diee_status diee_probe_dice(diee_ctx*, uint64_t seed, const uint32_t* ctr /*[n][4]*/, uint32_t n,
-                            uint8_t* dice /*[n][2]*/, double* uniform /*[n]*/);
-
-/* development probe: average device time (us, HIP events) of the 3x3 tower conv kernel without /
- * with the residual epilogue at batch G, and of a whole forward pass; variant 0 = geometry picked
- * by batch size; 1..4 per-layer (8x128ch/4 waves, 4x128/4, 2x64/2, 2x32/1 boards x channels/waves);
- * 5/6/7 and 17/18 split-K over 4 / 8 waves; 100..109 whole tower in one launch (fused geometries);
- * 201/202/204/208 cluster tower with 1/2/4/8 boards per cluster */
-diee_status diee_dev_conv_bench(diee_ctx*, int G, int variant, int reps, float* us_mode0,
-                                float* us_mode1, float* us_forward);
-/* development probe (stand-alone step kernel): average device time (us, HIP events) of one
- * get_valid_moves launch over n states already resident in HBM (one wave per state), and the mean number of plays */
-diee_status diee_dev_rules_bench(diee_ctx*, const diee_bg_state* states, uint32_t n, int reps,
-                                 float* us_legal_moves, float* mean_plays);
+/* Tensor::pow_(1 / temperature) as the self-play and arena drivers apply it to the visit distribution
+ * (alpha_parallel.rs:165, versus.rs:283): out[i] = x[i] ^ y[i] with the engine's deterministic powf (IEEE operations only,
+ * <= 1 ulp from libm, the same bits on the host oracle and on the GPU) */
+diee_status diee_det_pow(diee_ctx*, const float* x, const float* y, uint32_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,34 @@
+/*
+ * diee_dev.h -- development entry points of libdiee.so: arithmetic probes for the bit-exactness tests and kernel timing
+ * probes for scripts/.  NOT part of the drop-in boundary (include/diee.h): nothing on the product path (the Python package,
+ * the CLI, bench.py's timed region) calls these, and a binding of the reference does not need them.
+ */
+#ifndef DIEE_DEV_H
+#define DIEE_DEV_H
+#include "diee.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device arithmetic probes for the bit-exactness tests (f32 sqrt/div, det_pow, Philox dice) */
+diee_status diee_probe_f32(diee_ctx*, const float* a, const float* b, uint32_t n,
+                           float* sqrt_a, float* a_div_b, float* pow_ab);
+diee_status diee_probe_dice(diee_ctx*, uint64_t seed, const uint32_t* ctr /*[n][4]*/, uint32_t n,
+                            uint8_t* dice /*[n][2]*/, double* uniform /*[n]*/);
+
+/* development probe: average device time (us, HIP events) of the 3x3 tower conv kernel without /
+ * with the residual epilogue at batch G, and of a whole forward pass; variant 0 = geometry picked
+ * by batch size; 1..4 per-layer (8x128ch/4 waves, 4x128/4, 2x64/2, 2x32/1 boards x channels/waves);
+ * 5/6/7 and 17/18 split-K over 4 / 8 waves; 100..109 whole tower in one launch (fused geometries);
+ * 201/202/204/208 cluster tower with 1/2/4/8 boards per cluster */
+diee_status diee_dev_conv_bench(diee_ctx*, int G, int variant, int reps, float* us_mode0,
+                                float* us_mode1, float* us_forward);
+/* development probe (stand-alone step kernel): average device time (us, HIP events) of one
+ * get_valid_moves launch over n states already resident in HBM (one wave per state), and the mean number of plays */
+diee_status diee_dev_rules_bench(diee_ctx*, const diee_bg_state* states, uint32_t n, int reps,
+                                 float* us_legal_moves, float* mean_plays);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,5 +1,5 @@
 """Aggregate the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) into
-profiles/r01_pmc_traffic.json: mean KB per dispatch and kernel, FETCH_SIZE doubled (gfx950 correction for wide
+profiles/rNN_pmc_traffic.json: mean KB per dispatch and kernel, FETCH_SIZE doubled (gfx950 correction for wide
 coalesced read streams, MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported.
 
 usage: python scripts/pmc_traffic.py FETCH.csv WRITE.csv BOARDS OUT.json ["command line that was profiled"]"""

@@ -12,8 +12,8 @@ import diee_amd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "diee.h")).read()
+def header_symbols(name="diee.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(diee_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +29,37 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} is declared in include/diee.h but not exported by libdiee.so"
     assert sorted(diee_amd.EXPORTS) == syms, "die-e_amd.EXPORTS is out of sync with include/diee.h"
     assert b"gfx950" in L.diee_version()
+    # development probes live in their own header, not in the boundary
+    dev = header_symbols("diee_dev.h")
+    assert sorted(diee_amd.DEV_EXPORTS) == dev and all(hasattr(L, s) for s in dev)
+    assert not [s for s in syms if s.startswith(("diee_dev_", "diee_probe_"))]
+
+
+def test_header_compiles_as_c_and_layouts_match_the_ctypes_mirror(tmp_path):
+    """tests/abi_check.c: include/diee.h (+ diee_dev.h) compiled as C11 with _Static_asserts on the layouts a Rust
+    #[repr(C)] binding relies on; every offset it prints equals the ctypes mirror's"""
+    import json
+    import subprocess
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe])
+    doc = json.loads(subprocess.check_output([exe]).decode())
+    mirrors = {"diee_stats": diee_amd.Stats, "diee_fragments": diee_amd.Fragments, "diee_batch": diee_amd.Batch,
+               "diee_mcts_cfg": diee_amd.MctsConfig}
+    seen = 0
+    for key, off in doc.items():
+        st, field = key.split(".")
+        if st == "sizeof":
+            if field in mirrors:
+                assert C.sizeof(mirrors[field]) == off, key
+            elif field == "diee_bg_state":
+                assert diee_amd.BG_STATE.itemsize == off
+            continue
+        assert getattr(mirrors[st], field).offset == off, key
+        seen += 1
+    assert seen == 23 + 5 + 3
+    assert [n for n, _ in diee_amd.Stats._fields_] == [k.split(".")[1] for k in doc if k.startswith("diee_stats.")]
+
 
 
 def test_state_struct_is_32_bytes_and_matches_the_oracle(oracle):

@@ -74,15 +74,20 @@ def _ddp_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = orc.MctsCfg(iterations=4, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     r = orc.self_play_parallel(1, 2, cfg, 1.25, 3, orc.hash_eval_fn(), orc.game(1), first_game_id=2 * rank)
-    mem = {k: r[k][:8] for k in ("outcome", "ps", "state")}          # each rank trains on its own games
-    a = az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, 1, 8, 2), diee_amd.MctsConfig.default(4),
+    # each rank trains on its own games -- and on a DIFFERENT number of fragments (rank 0: 8 = 2 batches of 4, rank 1: 14 =
+    # 4 batches): ranks must take the same number of all-reduced steps (the minimum) or the longer one hangs in backward
+    take = 8 if rank == 0 else 14
+    assert len(r["outcome"]) >= 14
+    mem = {k: r[k][:take] for k in ("outcome", "ps", "state")}
+    a = az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, 1, 4, 2), diee_amd.MctsConfig.default(4),
                      az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0), train_device="cpu",
                      rank=rank, world=world, quiet=True)
     losses = a.train(mem)
     a.sync_engine()
     w = torch.from_numpy(a.blob.copy())
-    # BatchNorm running statistics are per-rank buffers (DDP broadcasts rank 0's at the next forward); compare parameters
-    q.put((rank, losses, float(w[:256 * 6 * 9].double().sum()), float(w[-1352 * 768 - 2500:-2500].double().sum())))
+    # sync_engine broadcasts rank 0's blob (BatchNorm running statistics are per-rank buffers): whole blobs must agree
+    import hashlib
+    q.put((rank, losses, float(w[:256 * 6 * 9].double().sum()), hashlib.sha256(a.blob.tobytes()).hexdigest()))
     dist.destroy_process_group()
 
 
@@ -101,5 +106,6 @@ def test_two_rank_ddp_training_step_gloo():
         assert p.exitcode == 0
     (_, l0, a0, b0), (_, l1, a1, b1) = res
     assert np.isfinite(l0 + l1).all()
+    assert len(l0) == len(l1) == 2     # min(ceil(8/4), ceil(14/4)) all-reduced steps on both ranks: nobody waits forever
     assert l0 != l1                    # different shards, different losses
-    assert a0 == a1 and b0 == b1       # identical parameters after the all-reduced step
+    assert a0 == a1 and b0 == b1       # identical blobs (parameters AND BatchNorm statistics) after sync_engine

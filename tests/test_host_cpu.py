@@ -154,3 +154,59 @@ def test_arena_driver_on_the_oracle_backends(oracle):
     assert res3.wins_p1 + res3.wins_p2 == 4
     with pytest.raises(NotImplementedError):
         versus.play(P(versus.Agent.MCTS), P(versus.Agent.RANDOM), diee_amd.MctsConfig.default(4), 1.25, num_games=2, rules=rules)
+
+
+def test_ot_archives_round_trip(tmp_path, oracle):
+    """F3: die-e's libtorch archives.  PARITY UNPINNED (the reference ships no .ot file, tch is not vendored): the
+    archives here are written by die-e_amd/ot.py itself -- in the variable order recalled from tch (bias before weight)
+    and in the other one -- and both load back to the same blob; training data goes through key "0" archives."""
+    import importlib
+    import torch
+    ot = importlib.import_module("die-e_amd.ot")
+    blob = diee_amd.random_weights(5)
+    p = str(tmp_path / "model.ot")
+    ot.save_model_ot(blob, p)
+    assert (ot.load_model_ot(p) == blob).all() and (ot.load_model(p) == blob).all()
+    names = [n for n, _ in ot.blob_to_named(blob)]
+    assert names[:6] == ["bias", "weight", "weight__2", "bias__3", "running_mean", "running_var"] and len(names) == 250
+    # weight-before-bias archives load too (the within-layer creation order of tch is recalled, not pinned)
+    alt, seen, off = [], set(), 0
+    for layer in ot._layers():
+        parts = {}
+        for base, shape in ot._layer_tensors(layer):
+            n = int(np.prod(shape)); parts[base] = torch.from_numpy(blob[off:off + n].reshape(shape).copy()); off += n
+        for base, _ in ot._layer_tensors(layer):
+            alt.append((base if base not in seen else f"{base}__{len(alt)}", parts[base])); seen.add(base)
+    p2 = str(tmp_path / "model_wb.ot")
+    ot._save_named(alt, p2)
+    assert (ot.load_model_ot(p2) == blob).all()
+    # an archive of another network is refused, not silently mis-assigned
+    ot._save_named(alt[:-1], p2)
+    with pytest.raises(ValueError):
+        ot.load_model_ot(p2)
+    # training data: ps.ot / states.ot / outcomes.ot (alphazero.rs:149-200), through AlphaZero.save/load_training_data
+    mem = small_memory(oracle)
+    d = tmp_path / "sp-0"; d.mkdir()
+    az.AlphaZero.save_training_data(mem, str(d), fmt="ot")
+    assert sorted(os.listdir(d)) == ["outcomes.ot", "ps.ot", "states.ot"]
+    back = az.AlphaZero.load_training_data(str(d))
+    assert back["ps"].tobytes() == mem["ps"].tobytes() and back["state"].tobytes() == mem["state"].tobytes()
+    assert (back["outcome"] == mem["outcome"]).all() and back["outcome"].dtype == np.int8
+    d2 = tmp_path / "npy"
+    ot.convert_data_dir(str(d), str(d2), to="npy")
+    assert np.load(d2 / "states.npy").shape == (len(mem["outcome"]), 6, 4, 6)
+    # the model loader of the learn / play / train commands takes either format
+    a = az.AlphaZero.from_config(None, {"temperature": 1.25, "learn_iterations": 1, "num_epochs": 1, "training_batch_size": 8,
+                                        "self_play_iterations": 1, "num_self_play_batches": 2, "iterations": 4,
+                                        "exploration_const": 2.0, "simulate_round_limit": 400, "dirichlet_alpha": 0.3,
+                                        "dirichlet_epsilon": 0.25, "wd": 1e-4, "lr": 1e-3}, model_path=p, train_device="cpu", quiet=True)
+    assert (a.blob == blob).all()
+
+
+def test_train_reshuffles_every_epoch(oracle):
+    """memory.shuffle(&mut thread_rng()) per train() call (alphazero.rs:203-204): consecutive epochs see different batches"""
+    conf = az.AlphaZeroConfig(1.25, 1, 1, 2, 4, 3)
+    a = az.AlphaZero(None, conf, diee_amd.MctsConfig.default(4), az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0),
+                     train_device="cpu", quiet=True)
+    p1 = a.shuffle_rng.permutation(32); p2 = a.shuffle_rng.permutation(32)
+    assert (p1 != p2).any()

@@ -44,7 +44,7 @@ def test_forward_matches_fp32_reference(setup, oracle):
     # relative check on the probabilities that matter
     rel = (np.abs(pol - rp) / rp).max()
     print(f"max relative policy error {rel:.3e}")
-    assert rel < 0.08
+    assert rel < 0.02          # measured 4e-3 .. 6e-3 on every dispatch path (round 2): 3 x measured
 
 
 def test_rows_are_independent_of_batch_composition(setup, oracle):
@@ -152,7 +152,7 @@ def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
     assert np.abs(p - p0).max() < 2e-5 and np.abs(v - v0).max() < 5e-3
     rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:32]))
     assert np.abs(p[:32] - rp).max() <= POLICY_ATOL and np.abs(v[:32] - rv).max() <= VALUE_ATOL
-    assert (np.abs(p[:32] - rp) / rp).max() < 0.08
+    assert (np.abs(p[:32] - rp) / rp).max() < 0.02
     # row independence within the geometry
     p2, v2 = e.forward_t(states[::-1].copy())
     assert (p2[::-1] == p).all() and (v2[::-1] == v).all()
@@ -242,7 +242,7 @@ def test_cluster_tower_two_contexts_on_one_gpu(oracle):
 PATHS = [("k_tower16<4,8,3>", 1024), ("k_tower16<4,8,6>", 700), ("k_tower16<2,8,9>", 300),
          ("k_tower_cl<8,4>", 200), ("k_tower_cl<4,8>", 100), ("k_tower_cl<2,8>", 50), ("k_tower_cl<1,8>", 20)]
 # measured on MI355X (round 2, 1024 mid-game states, random-init seed-0 net): see DESIGN.md section 2; bounds = 3 x measured
-PATH_POLICY_ATOL, PATH_VALUE_ATOL, PATH_POLICY_REL = 2e-3, 1e-2, 0.08
+PATH_POLICY_ATOL, PATH_VALUE_ATOL, PATH_POLICY_REL = 2e-5, 8e-3, 0.02
 
 
 @pytest.fixture(scope="module")
@@ -350,4 +350,5 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     print(f"[nn-parity] search fp32 vs bf16, {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.3f}, "
           f"TV mean {tv.mean():.4f} / p95 {np.quantile(tv, 0.95):.4f} / max {tv.max():.4f}, identical support {same_support:.3f}")
     assert same_support == 1.0                  # legal plays are integer work: identical
-    assert agree >= 0.80 and tv.mean() <= 0.08 and np.quantile(tv, 0.95) <= 0.25
+    # measured (round 2): agreement 0.992, TV mean 0.0010, p95 0.0100, max 0.0183; bounds = 3 x measured
+    assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.06
