@@ -27,10 +27,36 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_
 FLOPS_PER_EVAL = 1_082_450_064
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64):
+def host_cores():
+    """CPUs this process may really use: the affinity mask and the cgroup quota, not the machine's core count (a GPU box
+    gives one GPU's share of the host, e.g. 16 of 128 threads; an OpenMP pool sized to the machine then spins 8-fold
+    oversubscribed and a conv takes 100x longer)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    if "DIEE_CPU_THREADS" in os.environ:
+        n = max(1, int(os.environ["DIEE_CPU_THREADS"]))
+    return n
+
+
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
-    `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike).
+    `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
+    iterations of the sample is cut so that each variant takes about `budget_s` seconds on this host.
 
       B-ref  as die-e runs self-play today: ONE batched search over all roots, tree loops on one thread
              (alpha_mcts.rs:153-168,192-200), the network batch on every core (libtorch intra-op pool);
@@ -46,41 +72,50 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64):
     from oracle import nn_ref
     orc.build()
     net = nn_ref.parse(diee_amd.random_weights(0))
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     walk = orc.random_walk_states(seed & 0xFFFF, 40)
     roots = walk[np.linspace(3, len(walk) - 1, n_roots).astype(int)]
-    cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
 
     def fn(states_u8):
         st = states_u8.view(orc.BG_STATE).reshape(-1)
         pol, val, _ = nn_ref.forward_t(net, orc.planes_batch(st))
         return pol, val
 
-    def search(states, first_id):
+    def search(states, first_id, iters):
+        cfg = orc.MctsCfg(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
         ev = orc.make_eval(fn, 1352)
         n = len(states)
         _, _, st, _ = orc.alpha_mcts_parallel(1, states, cfg, ev, None, seed, 0, np.arange(first_id, first_id + n, dtype=np.uint32),
                                               np.zeros(n, dtype=np.uint32), 1)
         return st.as_dict()
 
-    out = {"unit": "games/s", "kind": "port", "cores": cores, "variants": {}}
+    def calibrate(states):
+        fn(states.view(np.uint8).reshape(-1, 32))                           # warm-up (primitive creation)
+        t = time.time(); fn(states.view(np.uint8).reshape(-1, 32)); return max(time.time() - t, 1e-4)
+
+    out = {"unit": "games/s", "kind": "port", "cores": cores, "host_threads_visible": os.cpu_count(), "variants": {}}
     # B-ref
     torch.set_num_threads(cores)
-    t = time.time(); st = search(roots, 0); dt = time.time() - t
+    it_ref = int(max(2, min(iterations, budget_s / calibrate(roots) - 1)))
+    t = time.time(); st = search(roots, 0, it_ref); dt = time.time() - t
     out["variants"]["B-ref"] = {
-        "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores,
+        "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores, "iterations_of_the_sample": it_ref,
         "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
         "what": f"one batched search over {n_roots} roots (serial C tree loops + fp32 PyTorch CPU ResNet on {cores} intra-op threads)"}
     # B-omp
     torch.set_num_threads(1)
     workers = max(1, min(cores, n_roots))
-    t = time.time()
+    per_thread = -(-n_roots // workers)                                     # roots a thread searches one after the other
     with cf.ThreadPoolExecutor(workers) as ex:
-        sts = list(ex.map(lambda i: search(roots[i:i + 1], i), range(n_roots)))
-    dt = time.time() - t
+        t = time.time(); list(ex.map(lambda i: calibrate(roots[i:i + 1]), range(workers)))      # per-evaluation time with every thread busy
+        t_eval = (time.time() - t) / 2
+        it_omp = int(max(2, min(iterations, budget_s / (t_eval * per_thread) - 1)))
+        t = time.time()
+        sts = list(ex.map(lambda i: search(roots[i:i + 1], i, it_omp), range(n_roots)))
+        dt = time.time() - t
     exps = sum(s["expansions"] for s in sts)
     out["variants"]["B-omp"] = {
-        "expansions_per_s": exps / dt, "seconds": dt, "threads": workers,
+        "expansions_per_s": exps / dt, "seconds": dt, "threads": workers, "iterations_of_the_sample": it_omp,
         "mean_children": sum(s["children"] for s in sts) / max(exps, 1),
         "mean_leaf_depth": sum(s["depth_sum"] for s in sts) / max(sum(s["selections"] for s in sts), 1),
         "what": f"{n_roots} independent searches, one per host thread ({workers} threads), batch-1 fp32 evaluations on that thread"}
@@ -91,10 +126,28 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64):
     out["value"] = eps / exp_per_game if exp_per_game else None
     out["cores"] = out["variants"][best]["threads"]
     out["sample"] = (f"{best} (the faster of B-ref / B-omp, both in `variants`): oracle (C restatement of the reference's tree / game "
-                     f"loops) + PyTorch fp32 CPU ResNet, one move-step of search (iterations={iterations}) on {n_roots} positions "
+                     f"loops) + PyTorch fp32 CPU ResNet, one move-step of search (iterations cut to "
+                     f"{out['variants'][best]['iterations_of_the_sample']} of {iterations} to fit ~{budget_s:.0f} s) on {n_roots} positions "
                      f"drawn evenly from random self-play walks (opening to bear-off); games/s extrapolated with the GPU run's "
                      f"{exp_per_game:.0f} expansions per game")
     return out
+
+
+def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=240):
+    """cpu_baseline in a child process (its own thread-pool settings; killed by PID after timeout_s): the baseline is a
+    report and must never hang the bench line"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--iterations", str(iterations),
+           "--seed", str(seed), "--exp-per-game", repr(float(exp_per_game))]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        why = f"rc {p.returncode}: {p.stderr.decode()[-300:]}"
+    except subprocess.TimeoutExpired:
+        why = f"no result within {timeout_s} s"
+    return {"value": None, "unit": "games/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {why}"}
 
 
 def main():
@@ -107,9 +160,14 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--exp-per-game", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--pipeline", type=int, default=4, help="also time K batches played side by side through diee_self_play_multi "
                     "(self_play_iterations of the learn loop; 0 = skip); reported as value_pipelined, never as value")
     args = ap.parse_args()
+    if args.cpu_baseline_only:                   # child of cpu_baseline_guarded: CPU only, never touches the GPU
+        print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game)))
+        return
 
     import importlib
     ddist = importlib.import_module("die-e_amd.dist")
@@ -189,9 +247,9 @@ def main():
     if rank == 0:
         games = tot["games"]
         exp_per_game = tot["expansions"] / max(games, 1)
-        def pmc_traffic(name, fname="r01_pmc_traffic.json"):
+        def pmc_traffic(name, fname="r02_pmc_traffic.json"):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/r01_pmc_traffic*.json; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
+            # (profiles/r02_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
@@ -219,7 +277,7 @@ def main():
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],
-                         pmc_traffic("diee::k_tower_cl<1", "r01_pmc_traffic_32boards.json"))
+                         pmc_traffic("diee::k_tower_cl<1", "r02_pmc_traffic_32boards.json"))
         r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; only when the other two are disabled)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
@@ -255,11 +313,7 @@ def main():
                 "fused_tower_avg_launch_us": (pipe["tower_seconds"] / max(pipe["tower_launches"], 1) * 1e6) if pipe["tower_seconds"] else None,
             }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.iterations, args.seed, exp_per_game)
-            except Exception as e:                   # the baseline is a report, never a reason to lose the line
-                out["cpu_baseline"] = {"value": None, "unit": "games/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
+            out["cpu_baseline"] = cpu_baseline_guarded(args.iterations, args.seed, exp_per_game)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

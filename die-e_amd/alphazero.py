@@ -190,6 +190,19 @@ class AlphaZero:
         self.last_stats = out["stats"]
         return {"outcome": out["outcome"], "ps": out["ps"], "state": out["state"]}
 
+    def self_play_iterations_pipelined(self):
+        """the `for sp_i in 0..self_play_iterations` loop of learn_parallel (alpha_parallel.rs:49-62) as ONE
+        diee_self_play_multi call: the calls share the network, so they are played side by side (same seeds, game ids
+        and per-call outputs as the sequential calls; the GPU does not idle through each call's tail)"""
+        n, K = self.config.num_self_play_batches, self.config.self_play_iterations
+        batches = []
+        for _ in range(K):
+            self.calls += 1
+            batches.append((n, self.rank * n, self.seed + 0x9E3779B1 * self.calls))
+        outs = self.engine.self_play_multi(batches, self.mcts_config, self.config.temperature, ref_quirks=True)
+        self.last_stats = outs[-1]["stats"]
+        return [{"outcome": o["outcome"], "ps": o["ps"], "state": o["state"]} for o in outs]
+
     # ---- save/load_training_data, alphazero.rs:149-200 (ps [M,1352], states [M,6,4,6], outcomes [M] i8) ----
     @staticmethod
     def save_training_data(memory, path, fmt=None):
@@ -279,7 +292,7 @@ class AlphaZero:
             self.engine.load_weights(self.blob)
 
     # ---- learn_parallel, alpha_parallel.rs:17-99 ----
-    def learn_parallel(self, arena=True, arena_games=400):
+    def learn_parallel(self, arena=True, arena_games=400, pipelined=True):
         run_id = secrets.token_urlsafe(16)[:21]                                 # nanoid!()
         base = os.path.join(self.root, "data", "backgammon", f"run-{run_id}")
         if self.rank == 0:
@@ -290,8 +303,9 @@ class AlphaZero:
             lrn = os.path.join(base, f"lrn-{l_i}")
             memory = []
             t_sp = time.time()
+            played = self.self_play_iterations_pipelined() if pipelined and hasattr(self.engine, "self_play_multi") else None
             for sp_i in range(self.config.self_play_iterations):                # :49
-                memory.append(self.self_play_parallel())
+                memory.append(played[sp_i] if played is not None else self.self_play_parallel())
                 if self.rank == 0:
                     sp_dir = os.path.join(lrn, f"sp-{sp_i}")
                     os.makedirs(sp_dir, exist_ok=True)

@@ -63,3 +63,43 @@ def test_learn_iteration_smoke(oracle, tmp_path):
     assert verdict in ("new model was better!", "current best model is still better!",
                        "new model vs current best was inconclusive, keeping current best!")
     eng.close()
+
+
+def test_cli_end_to_end_in_a_child_process(tmp_path):
+    """F4: `diee.py -c tiny.toml -g backgammon learn | train | play` driven like die-e's binary (main.rs:15-216), a fresh
+    child process per command; the model handed to `learn` is a libtorch-style .ot archive (F3)"""
+    import os
+    import subprocess
+    import sys
+    import diee_amd
+    ot = importlib.import_module("die-e_amd.ot")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = tmp_path / "tiny.toml"
+    cfg.write_text("temperature = 1.25\nlearn_iterations = 1\nnum_epochs = 1\ntraining_batch_size = 16\nself_play_iterations = 2\n"
+                   "num_self_play_batches = 6\niterations = 4\nexploration_const = 2.0\nsimulate_round_limit = 30\n"
+                   "dirichlet_alpha = 0.3\ndirichlet_epsilon = 0.25\nwd = 0.0001\nlr = 0.001\n")
+    model = tmp_path / "start.ot"
+    ot.save_model_ot(diee_amd.random_weights(2), str(model))
+
+    def run(*args):
+        p = subprocess.run([sys.executable, os.path.join(root, "diee.py"), "-c", str(cfg), "-g", "backgammon", *args],
+                           cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        return p.returncode, p.stdout.decode()
+    rc, out = run("learn", "-m", str(model))
+    assert rc == 0, out
+    assert "Staring up run with run_id" in out and "Iteration 0 saved successfully" in out
+    mdir = tmp_path / "models" / "backgammon"
+    assert (mdir / "model_0.npy").exists() and (mdir / "best_model.npy").exists()
+    run_dir = next((tmp_path / "data" / "backgammon").iterdir())
+    assert sorted(p.name for p in (run_dir / "lrn-0").iterdir()) == ["sp-0", "sp-1"]
+    # train on everything that run wrote (main.rs:172-207), saving a .ot archive
+    rc, out = run("train", "-r", run_dir.name[len("run-"):], "-o", str(tmp_path / "trained.ot"))
+    assert rc == 0 and "Trained model saved successfully" in out, out
+    assert ot.load_model_ot(str(tmp_path / "trained.ot")).size == diee_amd.weights_count()
+    # play: Model (the .ot archive) against Random, 400 games of the arena are too many here -> the agents' surface only
+    games = tmp_path / "games"; games.mkdir()
+    rc, out = run("play", "-a", "Random", "--agent-two", "Random", "-o", str(games))
+    assert rc == 0 and "Saving games" in out, out
+    assert len(list(games.iterdir())) == 400                                      # versus.rs:160: 400 games
+    rc, out = run("replay", "-g", str(next(games.iterdir())))
+    assert rc == 0 and "Player 1: Random" in out
