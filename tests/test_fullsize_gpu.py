@@ -74,3 +74,34 @@ def test_full_size_batch_invariants(eng):
     # only slot 0 can additionally collect the stale-initial re-backprops of other games
     assert (r["root_visits"][1:] <= 201).all()
     assert (r["root_visits"] == 101).mean() > 0.5
+
+
+def test_config4_deep_tree_full_size_properties(eng, oracle):
+    """BASELINE configs[3] at its full size: 1024 roots x iterations = 1600 (205 k-node arenas, 11.8 GB of tree), through
+    size-independent properties: visit distributions sum to 1 over the legal codes only, root visits = iterations + 1
+    (+ Q14 extras), every selection is counted, children match the legal-play counts of the roots, mean leaf depth > 2"""
+    import diee_amd
+    iters = 1600
+    cfg = diee_amd.MctsConfig(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    roots = oracle.random_walk_states(99, 40)
+    roots = roots[np.linspace(0, len(roots) - 1, 1024).astype(int)]
+    r = eng.alpha_mcts_parallel(roots, cfg, 0xD1EE0001, 0)
+    st = r["stats"]
+    assert st["selections"] == iters * 1024 and st["illegal_decodes"] == 0
+    assert st["nn_evals"] == (iters + 1) * 1024
+    assert st["expansions"] + st["terminal_hits"] <= (iters + 1) * 1024
+    assert st["depth_sum"] / st["selections"] > 2.0                  # a deep tree, not a wide root
+    plays, counts = eng.get_valid_moves(roots, 160)
+    assert (r["n_children"] == counts).all()                         # root children = legal plays of the root (A2 = M6)
+    has = counts > 0
+    assert np.allclose(r["probs"][has].sum(1), 1.0, atol=1e-5) and np.isnan(r["probs"][~has]).all()
+    idx_s, idx_p = np.nonzero(np.arange(160)[None, :] < counts[:, None])
+    legal = np.zeros((1024, 1352), dtype=bool)
+    legal[idx_s, eng.encode(roots[idx_s], plays[idx_s, idx_p])] = True
+    assert (np.nan_to_num(r["probs"])[~legal] == 0).all()            # visits only on legal codes
+    rv = r["root_visits"]
+    assert (rv >= iters + 1).all() and (rv[1:] <= 2 * iters + 1).all()
+    # every visit below the root was a selection: sum of child visits = root visits - 1 is implied by rows summing to 1;
+    # check the distribution is not degenerate: the most visited child holds less than everything when there is a choice
+    multi = counts > 1
+    assert (np.nan_to_num(r["probs"])[multi].max(1) < 1.0).all()
