@@ -228,11 +228,11 @@ def main():
         sts = [o["stats"] for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=False, max_steps=args.max_steps)]
         barrier()
         dtp = time.perf_counter() - tp0
-        pipe = {k: sum(st[k] for st in sts) for k in ("games", "expansions", "nn_evals", "plies", "fragments")}
+        pipe = {k: sum(st[k] for st in sts) for k in ("games", "expansions", "nn_evals", "nn_rows", "plies", "fragments")}
         pipe["move_steps"] = max(st["move_steps"] for st in sts)
         pipe["tower_seconds"], pipe["tower_launches"], pipe["tower_flops"] = (sts[0][k] for k in ("tower_seconds", "tower_launches", "tower_flops"))
 
-    keys = ["games", "expansions", "nn_evals", "plies", "move_steps", "children", "selections", "depth_sum",
+    keys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
             "fragments", "illegal_decodes"]
@@ -240,7 +240,7 @@ def main():
         dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
         tot.update(red)
         if pipe is not None:
-            pkeys = ["games", "expansions", "nn_evals", "plies", "fragments", "tower_seconds", "tower_launches", "tower_flops"]
+            pkeys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "fragments", "tower_seconds", "tower_launches", "tower_flops"]
             dtp, red = ddist.reduce_stats(dist, dtp, pipe, pkeys, "cuda")
             pipe.update(red)
 
@@ -291,8 +291,10 @@ def main():
                                    "simulate_round_limit=400, dirichlet 0.3/0.25, random-init 19x256 ResNet (seed 0), "
                                    "ref_quirks on" + (f", TRUNCATED to {args.max_steps} move-steps per batch (profiling run)" if args.max_steps else ""), "parallelism": f"dp{world} (independent games, no collective)"},
             "node_expansions_per_s": tot["expansions"] / dt,
-            "nn_evals_per_s": tot["nn_evals"] / dt,
-            "mfma_fraction_end_to_end": tot["nn_evals"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world),
+            # nn_evals = batch rows as the reference counts them (all N slots per iteration, stale rows included);
+            # nn_rows = rows the engine really evaluated (stale rows are skipped above 256 live games)
+            "nn_evals_per_s": tot["nn_evals"] / dt, "nn_rows_per_s": tot["nn_rows"] / dt,
+            "mfma_fraction_end_to_end": tot["nn_rows"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world),
             "stats": {"games": games, "plies_per_game": tot["plies"] / max(games, 1), "move_steps": tot["move_steps"],
                       "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
@@ -308,7 +310,8 @@ def main():
                         "batches share every network launch, each keeps its own seed / Dirichlet stream / Q14 bookkeeping",
                 "batches": args.pipeline, "seconds": dtp, "games": pipe["games"], "move_steps": pipe["move_steps"],
                 "node_expansions_per_s": pipe["expansions"] / dtp, "nn_evals_per_s": pipe["nn_evals"] / dtp,
-                "mfma_fraction_end_to_end": pipe["nn_evals"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
+                "nn_rows_per_s": pipe["nn_rows"] / dtp,
+                "mfma_fraction_end_to_end": pipe["nn_rows"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
                 "fused_tower_tflops": (pipe["tower_flops"] / pipe["tower_seconds"] / 1e12) if pipe["tower_seconds"] else None,
                 "fused_tower_avg_launch_us": (pipe["tower_seconds"] / max(pipe["tower_launches"], 1) * 1e6) if pipe["tower_seconds"] else None,
             }

@@ -37,7 +37,12 @@ constexpr int kClusterMaxGroups = 64;
 // `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
-void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G);
+void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G,
+                      const uint32_t* n_rows = nullptr);   // n_rows non-null: device-side row count of a compacted batch (<= G)
+// fused tower over a batch compacted on the device: row_slot[row] = slot to evaluate, *n_rows rows (<= n_upper); see RowMap
+void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, int n_upper, const void* states,
+                          const void* winit16, const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv,
+                          const uint32_t* row_slot, const uint32_t* n_rows);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);
 
@@ -47,6 +52,10 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c);   // next_it: iteration to select for afterwards, kNoNextIteration = none
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
+// rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
+// count also goes to rows_log[log_idx])
+void launch_row_map(hipStream_t st, const uint8_t* skip, uint32_t n, uint32_t* row_slot, uint32_t* slot_row, uint32_t* n_rows,
+                    uint32_t* rows_log, uint32_t log_idx);
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits);
 void launch_init_games(hipStream_t st, const Games& Gm, const Segs& G, uint32_t n);
 void launch_gather_roots(hipStream_t st, const Games& Gm, const Slots& S, const Segs& G, uint32_t n_live);

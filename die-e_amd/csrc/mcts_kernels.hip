@@ -181,6 +181,9 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     if (active) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
     if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] += G.end_slot[seg] - seg_first;
+    // the row of this slot in the network outputs (a compacted batch holds only the slots whose leaf was not terminal)
+    const uint32_t row = S.slot_row ? S.slot_row[slot] : slot;
+    if (lane == 0 && (root || S.slot_row == nullptr || !S.leaf_term[slot])) S.slot_cnt[slot * SC_COUNT + SC_NN_ROWS] += 1;
 
     uint32_t node = 0;
     float v = 0.0f;
@@ -196,11 +199,11 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             }
         } else {
             node = S.leaf[slot];
-            v = value_head(S.hv + (size_t)slot * 72, S.wv, lane);       // the value head's FC + tanh (nn_device.h)
+            v = value_head(S.hv + (size_t)row * 72, S.wv, lane);        // the value head's FC + tanh (nn_device.h)
             if (lane == 0) S.sel_value[slot] = v;
         }
     } else if (slot == seg_first) {
-        const float v0 = value_head(S.hv + (size_t)slot * 72, S.wv, lane);
+        const float v0 = value_head(S.hv + (size_t)row * 72, S.wv, lane);
         if (lane == 0) S.root_value0[seg] = v0;
     }
     const uint32_t m0 = T.meta[base + node];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
         const BgState st = load_state(&T.state[base + node]);
         const int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
         const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
-        const float* lrow = S.logits + (size_t)slot * 1352;
+        const float* lrow = S.logits + (size_t)row * 1352;
         float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
         softmax_consts(lrow, lane, smM, smInv);
         const float om = 1.0f - P.dir_eps;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
     }
     __syncthreads();
     if (tid == 0) {
-        const int map[SC_COUNT] = {CNT_SELECTIONS, CNT_DEPTH_SUM, CNT_TERMINAL, CNT_EXPANSIONS, CNT_CHILDREN, CNT_MAX_CHILDREN, CNT_ILLEGAL};
+        const int map[SC_COUNT] = {CNT_SELECTIONS, CNT_DEPTH_SUM, CNT_TERMINAL, CNT_EXPANSIONS, CNT_CHILDREN, CNT_MAX_CHILDREN, CNT_ILLEGAL, CNT_NN_ROWS};
         unsigned long long* cnt = S.counters + (size_t)seg * CNT_COUNT;
         for (int c = 0; c < SC_COUNT; ++c) {
             unsigned long long t = 0;
@@ -311,6 +314,37 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
             else cnt[map[c]] += t;
         }
     }
+}
+
+// ---- rows of the next network evaluation -------------------------------------------------------
+// The reference pushes all N slots through the network every iteration (alpha_mcts.rs:175-183) although the rows of
+// slots whose selected leaf was terminal are stale and their results are never read (the engine keeps the value such a
+// slot needs, Slots::sel_value).  Above 256 live games the engine evaluates only the slots with skip[slot] == 0, in slot
+// order (stable, so a slot's row depends on nothing but the flags): row_slot[row] = slot, slot_row[slot] = row.
+// One block; the network launches that follow read *n_rows on the device, the host never sees it.
+__global__ __launch_bounds__(1024) void k_row_map(const uint8_t* __restrict__ skip, uint32_t n, uint32_t* __restrict__ row_slot,
+                                                  uint32_t* __restrict__ slot_row, uint32_t* __restrict__ n_rows,
+                                                  uint32_t* __restrict__ rows_log, uint32_t log_idx) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024) {
+        const uint32_t i = c0 + tid;
+        const bool keep = i < n && skip[i] == 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const uint32_t pos = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) { row_slot[pos] = i; slot_row[i] = pos; }
+        __syncthreads();
+        if (tid == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; carry += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { *n_rows = carry; if (rows_log) rows_log[log_idx] = carry; }
 }
 
 // ---- get_prob_tensor_parallel, utils.rs:42-58 --------------------------------------------------
@@ -514,6 +548,10 @@ void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);
+}
+void launch_row_map(hipStream_t st, const uint8_t* skip, uint32_t n, uint32_t* row_slot, uint32_t* slot_row, uint32_t* n_rows,
+                    uint32_t* rows_log, uint32_t log_idx) {
+    hipLaunchKernelGGL(k_row_map, dim3(1), dim3(1024), 0, st, skip, n, row_slot, slot_row, n_rows, rows_log, log_idx);
 }
 void launch_root_probs(hipStream_t st, const Tree& T, uint32_t n, float* probs, uint32_t* nch, float* root_visits) {
     hipLaunchKernelGGL(k_root_probs, dim3(n), dim3(64), 0, st, T, n, probs, nch, root_visits);

@@ -149,6 +149,7 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;
     if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
+    if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
     if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
         net->cluster_table.clear();
         std::string t(v);
@@ -307,7 +308,7 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
 
 // the convolutional part of the network (init block, 38-layer tower, head convs) for rows [off, off + G) of the batch:
 // states -> hp / hv.  The tower kernel is picked by G alone (tower_table / cluster_table).
-static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G) {
+static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, bool fused_family = false) {
     NetWeights& W = *e.net;
     hipStream_t st = e.stream;
     const void* states_dev = (const uint8_t*)states_all + (size_t)off * 32;
@@ -316,7 +317,8 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G) {
     uint16_t* hp = W.hp.p + (size_t)off * 768;
     float* hv = W.hv.p + (size_t)off * 72;
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
-    const int tgeom = W.tower_geometry_for(G);
+    int tgeom = W.tower_geometry_for(G);
+    if (tgeom < 0 && fused_family) tgeom = 3;                   // the remainder of a batch above 256 boards: never the split-K family
     static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
     const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch (development)
     // sampled timing of the tower: one HIP-event pair per sampled forward (per-launch pairs cost ~4.6 us each and
@@ -371,32 +373,57 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G) {
                 kind == 1 ? "fused tower" : kind == 2 ? "cluster tower" : "per-layer kernels", tgeom, W.tower_table.size(), W.cluster_table.size());
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind});
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind, -1});
     }
     if (!whole && !heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
 // More boards than one pass of the chip holds (256 CUs x 4 boards): the whole multiples of kFullChip go through ONE
-// launch of the 4-board fused tower (its workgroups run in full rounds), the remainder through the kernel that is
-// fastest at the remainder's size -- a partial last round of 4-board workgroups would cost a full round.
-void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev) {
+// launch of the 4-board fused tower (its workgroups run in full rounds), the remainder through the fused geometry that is
+// fastest at the remainder's size -- a partial last round of 4-board workgroups would cost a full round.  Above 256
+// boards every launch is of the fused 16x16x32 family, so a row's result does not depend on where in the batch it sits
+// (below, the latency-optimised split-K cluster tower takes the whole batch).
+//
+// rows != nullptr: the batch is COMPACTED on the device (search iterations above 256 live games): only the slots with
+// rows->skip[slot] == 0 are evaluated, row r of the outputs belongs to slot rows->row_slot[r]; returns true when it did so
+// (the caller then reads outputs through rows->slot_row).
+bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev, const NnRows* rows) {
     if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
-    if (G <= 0) return;
+    if (G <= 0) return false;
     NetWeights& W = *e.net;
     nn_reserve(e, G);
     hipStream_t st = e.stream;
+    const int tg = W.tower_geometry_for(G);
+    if (rows && W.compact && !policy_dev && G > W.compact_above && tg >= 2 && W.cluster_init && W.fused_heads && !W.net16) {
+        const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
+        const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
+        W.rows_log.ensure(kRowsLog);
+        launch_row_map(st, rows->skip, (uint32_t)G, rows->row_slot, rows->slot_row, rows->n_rows, W.rows_log.p, seq);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
+        launch_tower_compact(st, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
+                             W.hp.p, W.hv.p, rows->row_slot, rows->n_rows);
+        if (sample) {
+            HIPCHK(hipEventRecord(ev1, st));
+            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq});     // flops per ROW: the row count is in rows_log[seq]
+        }
+        launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G, rows->n_rows);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
     const int full = W.full_chip_boards;
     int main_rows = G;
-    if (full > 0 && G > full && W.tower_geometry_for(G) >= 0) {
+    if (full > 0 && G > full && tg >= 0) {
         main_rows = G / full * full;
-        if (W.tower_geometry_for(G - main_rows) == W.tower_geometry_for(G)) main_rows = G;   // the remainder would take the same kernel
+        if (W.tower_geometry_for(G - main_rows) == tg) main_rows = G;   // the remainder would take the same kernel
     }
     nn_conv_chunk(e, states_dev, 0, main_rows);
-    if (main_rows < G) nn_conv_chunk(e, states_dev, main_rows, G - main_rows);
+    if (main_rows < G) nn_conv_chunk(e, states_dev, main_rows, G - main_rows, true);
     launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
     if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
+    return false;
 }
 
 // the cluster tower ran since the last call (its hand-over flag is worth a look)
@@ -431,8 +458,14 @@ NetHeads nn_heads(Engine& e, int G) {
 void nn_harvest(Engine& e, diee_stats* stats) {
     if (!e.net) return;
     NetWeights& W = *e.net;
+    std::vector<uint32_t> rows_log;
+    for (auto& p : W.pending) if (p.rows_seq >= 0 && rows_log.empty()) {
+        rows_log.resize(kRowsLog);
+        e.d2h(rows_log.data(), W.rows_log.p, (size_t)kRowsLog); e.sync();
+    }
     for (auto& p : W.pending) {
         float ms = 0.f;
+        if (p.rows_seq >= 0) p.flops *= (double)rows_log[(size_t)p.rows_seq];      // compacted batch: flops per row x rows evaluated
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 1) { W.tower_seconds += ms * 1e-3; W.tower_launches += p.launches; W.tower_flops += p.flops; }
             else if (p.kind == 2) { W.cluster_seconds += ms * 1e-3; W.cluster_launches += p.launches; W.cluster_flops += p.flops; }

@@ -50,7 +50,11 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; };   // kind 0 per-layer, 1 fused tower, 2 cluster tower
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower, 2 cluster
+                                    // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
+    bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
+    int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)
+    DevBuf<uint32_t> rows_log;      // [kRowsLog] rows evaluated by the compacted forward number (forward_count mod kRowsLog)
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     int sample_every = 17;
@@ -67,10 +71,14 @@ struct NetWeights {
     }
 };
 
+constexpr uint32_t kRowsLog = 1u << 20;
+// device-side description of a compacted batch (owned by the search): skip[slot] != 0 = no evaluation needed;
+// k_row_map fills row_slot / slot_row / n_rows right before the network launches
+struct NnRows { const uint8_t* skip; uint32_t* row_slot; uint32_t* slot_row; uint32_t* n_rows; };
 void nn_reserve(Engine& e, int G);
 // policy_dev == nullptr: stop after the policy FC and the head convs; the caller (the search) finishes the softmax and the
 // value head itself from nn_heads() with the functions of nn_device.h (same bits, one launch less per evaluation)
-void nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev);
+bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev, const NnRows* rows = nullptr);
 struct NetHeads { const float* logits; const float* hv; const float* wv; };
 NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserved
 bool nn_cluster_used(Engine& e);

@@ -945,9 +945,28 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
     __syncthreads();
 }
 
+// Which boards a launch of the fused tower evaluates when the batch is COMPACTED on the device (the search skips the
+// slots whose selected leaf was terminal: their network row would be computed and never read).  row_slot[row] = slot of
+// the row-th slot that needs an evaluation, *n_rows = how many there are; both are written by k_row_map right before, so
+// the host does not know n_rows and launches up to three towers whose workgroups decide for themselves:
+//   mode 1  the whole passes of the chip: rows [0, main)      (4 boards per workgroup, full rounds of 256 workgroups)
+//   mode 2  the remainder [main, n_rows) if it has more than kRemSplit boards   (4 boards per workgroup)
+//   mode 3  the remainder if it has at most kRemSplit boards                    (2 boards per workgroup)
+// main = n_rows rounded down to a multiple of kFullChip (or n_rows itself if the rest would fill > 928 boards of a pass),
+// capped by what the host launched for mode 1.  All three are the same arithmetic per output element (the 16x16x32
+// fused family), so WHICH launch evaluates a row never shows in its result.
+constexpr int kFullChip = 1024, kRemSplit = 416, kFullRest = 928;
+struct RowMap {
+    const uint32_t* row_slot;   // null: rows are slots (no compaction)
+    const uint32_t* n_rows;
+    int mode;                   // 0 plain, 1 / 2 / 3 see above
+    int main_cap;               // boards the mode-1 launch of this evaluation can take (0: there is none)
+};
+
 template <int GT, int NW, int PF>
 __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict__ x_in, const u32x4* __restrict__ wt,
                                                     const float* __restrict__ bias, uint16_t* __restrict__ x_out, int M,
+                                                    RowMap rm,
                                                     unsigned long long* dbg /* clock stamps, diagnostic builds only */,
                                                     const BgState* __restrict__ states,   // non-null: the init block runs in here
                                                     const u32x4* __restrict__ winit,      // [16][9][64] x 16 B (pack_init16)
@@ -963,7 +982,22 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
     char* tx = smem;
     char* th = smem + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
+    int board0 = blockIdx.x * GT;
+    if (rm.mode != 0) {                                          // compacted batch: this launch's share of the rows
+        const int nr = (int)*rm.n_rows;
+        const int tail = nr % kFullChip;
+        int main_b = tail > kFullRest ? nr : nr - tail;
+        main_b = main_b < rm.main_cap ? main_b : rm.main_cap;
+        const int rest = nr - main_b;
+        int lo, hi;
+        if (rm.mode == 1) { lo = 0; hi = main_b; }
+        else if (rm.mode == 2) { lo = main_b; hi = rest > kRemSplit ? nr : main_b; }
+        else { lo = main_b; hi = rest <= kRemSplit ? nr : main_b; }
+        board0 += lo;
+        if (board0 >= hi) return;
+        M = hi * 24;
+    }
+    const int row0 = board0 * 24;
 
     const u32x4* wp0 = wt + (size_t)(wave * NFR) * 72 * 64 + lane;
     u32x4 bq[PF][NFR];
@@ -978,7 +1012,8 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
             const int r = i >> 2, ch = i & 3;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (ch == 0 && row0 + r < M) {
-                const BgState st = states[(row0 + r) / 24];
+                const int brd = (row0 + r) / 24;
+                const BgState st = states[rm.row_slot ? (int)rm.row_slot[brd] : brd];
                 const int p = (row0 + r) % 24;
                 uint32_t w[3];
 #pragma unroll
@@ -1337,9 +1372,10 @@ __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ h
                                                   const u32x4* __restrict__ wpack,   // [43][48][64] x 16 B
                                                   const float* __restrict__ bias,    // [1376]
                                                   float* __restrict__ logits,        // [G][1352]
-                                                  int G) {
+                                                  int G, const uint32_t* __restrict__ n_rows /* non-null: the rows of a compacted batch */) {
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * 32, nslice = blockIdx.y;
+    if (n_rows) { G = (int)*n_rows; if (g0 >= G) return; }
     int row = g0 + (lane & 31);
     const bool rok = row < G;
     if (!rok) row = G - 1;
@@ -1486,7 +1522,8 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
 template <int GT, int NW, int PF>
 static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G,
                            const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
-                           const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr) {
+                           const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr,
+                           const RowMap rm = RowMap{nullptr, nullptr, 0, 0}) {
     static bool attr_set = false;
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
@@ -1495,8 +1532,27 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
         attr_set = true;
     }
     hipLaunchKernelGGL((k_tower16<GT, NW, PF>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
-                       (const u32x4*)wt, bias, x_out, G * 24, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit,
+                       (const u32x4*)wt, bias, x_out, G * 24, rm, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit,
                        (const u32x4*)whead16, bhead, hp, hv);
+}
+
+// The fused tower over a batch compacted on the device (see RowMap): up to three launches, each workgroup decides from
+// *n_rows whether it has work.  n_upper = the host's upper bound of n_rows (the number of live slots).
+void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, int n_upper, const void* states,
+                          const void* winit16, const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv,
+                          const uint32_t* row_slot, const uint32_t* n_rows) {
+    const int tail = n_upper % kFullChip;
+    const int main_cap = n_upper < kFullChip ? 0 : (tail > kFullRest ? n_upper : n_upper - tail);
+    if (main_cap > 0)
+        tower16_launch<4, 8, 3>(st, nullptr, wt16, bias, nullptr, main_cap, states, winit16, binit, whead16, bhead, hp, hv,
+                                RowMap{row_slot, n_rows, 1, main_cap});
+    // the remainder launches go out whatever n_upper is: n_rows may fall short of it by any amount
+    const int rest_max = n_upper < kFullChip ? n_upper : kFullChip - 1;
+    if (rest_max > kRemSplit)
+        tower16_launch<4, 8, 6>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
+                                RowMap{row_slot, n_rows, 2, main_cap});
+    tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,
+                            binit, whead16, bhead, hp, hv, RowMap{row_slot, n_rows, 3, main_cap});
 }
 template <int GT, int NW, int PF>
 static void net16_launch(hipStream_t st, const Net16Params& P) {
@@ -1593,9 +1649,10 @@ void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, con
     else conv_sk_launch<2, 2>(st, act, wpack, bias, res, out, G, N, out_v);
 }
 
-void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G) {
+void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G,
+                      const uint32_t* n_rows) {
     if (G <= 0) return;
-    hipLaunchKernelGGL(k_policy_fc, dim3((G + 31) / 32, 43), dim3(64), 0, st, hp, (const u32x4*)wpack, bias, logits, G);
+    hipLaunchKernelGGL(k_policy_fc, dim3((G + 31) / 32, 43), dim3(64), 0, st, hp, (const u32x4*)wpack, bias, logits, G, n_rows);
 }
 
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,

@@ -25,7 +25,7 @@ struct SearchBufs {
     uint32_t node_cap = 0, slot_cap = 0;
     // slots
     DevBuf<BgState> roots, eval_states;
-    DevBuf<uint32_t> game_id, round, seg, leaf, sel, iter_flags;
+    DevBuf<uint32_t> game_id, round, seg, leaf, sel, iter_flags, row_slot, slot_row, n_rows;
     DevBuf<float> sel_value, noise, root_value0;
     DevBuf<uint8_t> leaf_term;
     DevBuf<unsigned long long> counters, counters_bak;
@@ -114,6 +114,7 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.used.ensure(sc);
         B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc); B.seg.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
+        B.row_slot.ensure(sc); B.slot_row.ensure(sc); B.n_rows.ensure(4);
         B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
     }
@@ -134,7 +135,7 @@ Tree tree_view(SearchBufs& B) {
 Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
-                 H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
+                 nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
 }
 Segs segs_view(SearchBufs& B, uint32_t n_segs) {
     return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};
@@ -165,10 +166,12 @@ void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint3
 void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, int buf, uint32_t flags) {
     SearchBufs& B = *e.search;
     const Tree T = tree_view(B);
-    const Slots S = slots_view(e, B);
+    Slots S = slots_view(e, B);
     const Segs G = segs_view(B, n_segs);
     hipStream_t st = e.stream;
     const uint32_t quirks = (flags & DIEE_FLAG_REF_QUIRKS) ? 1u : 0u;
+    // slots whose selected leaf was terminal need no network row: above 256 live games only the others are evaluated
+    const NnRows rows{B.leaf_term.p, B.row_slot.p, B.slot_row.p, B.n_rows.p};
     HIPCHK(hipMemsetAsync(B.iter_flags.p, 0, sizeof(uint32_t) * 2 * (size_t)B.iter_cap * n_segs, st));
     HIPCHK(hipMemcpyAsync(B.noise.p, B.noise_host + (size_t)buf * kMaxSegments * 1352, sizeof(float) * 1352 * n_segs,
                           hipMemcpyHostToDevice, st));
@@ -178,7 +181,8 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
     launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
-        nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);       // alpha_mcts.rs:186
+        const bool compacted = nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr, &rows);   // alpha_mcts.rs:186
+        S.slot_row = compacted ? B.slot_row.p : nullptr;
         launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
     }
     launch_reduce_counters(st, S, G);
@@ -208,7 +212,7 @@ void read_counters(Engine& e, uint32_t seg, diee_stats* stats) {
     stats->nn_evals = c[CNT_NN_EVALS]; stats->expansions = c[CNT_EXPANSIONS]; stats->children = c[CNT_CHILDREN];
     stats->terminal_hits = c[CNT_TERMINAL]; stats->depth_sum = c[CNT_DEPTH_SUM]; stats->selections = c[CNT_SELECTIONS];
     stats->illegal_decodes = c[CNT_ILLEGAL]; stats->max_children = c[CNT_MAX_CHILDREN];
-    stats->plies = c[CNT_PLIES]; stats->games = c[CNT_GAMES];
+    stats->plies = c[CNT_PLIES]; stats->games = c[CNT_GAMES]; stats->nn_rows = c[CNT_NN_ROWS];
 }
 
 struct InvariantScope {    // DIEE_FLAG_INVARIANT_NN for the duration of one call

@@ -19,11 +19,11 @@ namespace diee {
 
 enum Counter {
     CNT_NN_EVALS = 0, CNT_EXPANSIONS, CNT_CHILDREN, CNT_TERMINAL, CNT_DEPTH_SUM, CNT_SELECTIONS,
-    CNT_ILLEGAL, CNT_MAX_CHILDREN, CNT_PLIES, CNT_GAMES, CNT_COUNT
+    CNT_ILLEGAL, CNT_MAX_CHILDREN, CNT_PLIES, CNT_GAMES, CNT_NN_ROWS, CNT_COUNT
 };
 constexpr uint32_t kMaxSegments = 64;
 
-enum SlotCounter { SC_SELECTIONS = 0, SC_DEPTH_SUM, SC_TERMINAL, SC_EXPANSIONS, SC_CHILDREN, SC_MAX_CHILDREN, SC_ILLEGAL, SC_COUNT };
+enum SlotCounter { SC_SELECTIONS = 0, SC_DEPTH_SUM, SC_TERMINAL, SC_EXPANSIONS, SC_CHILDREN, SC_MAX_CHILDREN, SC_ILLEGAL, SC_NN_ROWS, SC_COUNT };
 
 struct Tree {
     float* visits;          // Node.visits  (f32 like the reference, node.rs:14)
@@ -57,6 +57,8 @@ struct Slots {
     uint32_t* sel;          // [slots] selected_nodes_idxs (persists over iterations; 0xFFFFFFFF = initial)
     float* sel_value;       // [slots] NN value of sel
     uint8_t* leaf_term;     // [slots] leaf was terminal this iteration
+    const uint32_t* slot_row;   // [slots] row of the slot's evaluation in the network outputs when the batch was compacted
+                                // (k_row_map: slots with a terminal leaf get no row); null = row == slot
     const float* logits;    // [slots][1352] policy logits of this iteration's evaluation (nn_host's buffers)
     const float* hv;        // [slots][72] value features
     const float* wv;        // [73] value FC

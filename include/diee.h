@@ -99,6 +99,8 @@ typedef struct {
     double   cluster_seconds;  /* HIP-event time of sampled cluster-tower launches (k_tower_cl, small batches) */
     uint64_t cluster_launches;
     double   cluster_flops;
+    uint64_t nn_rows;          /* rows the ResNet really evaluated: above 256 live games the rows of slots whose selected leaf
+                                  was terminal (stale in the reference, never read) are skipped; nn_evals keeps the reference's count */
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */

@@ -217,3 +217,30 @@ def test_mcts_batch_bit_exact_above_one_chip_pass(eng, oracle):
     gs, os_ = r["stats"], ostats.as_dict()
     for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
         assert gs[key] == os_[key], (key, gs[key], os_[key])
+
+
+def test_compacted_evaluation_changes_nothing_but_the_row_count(oracle, monkeypatch):
+    """above 256 live games the engine evaluates only the slots whose selected leaf was not terminal (the reference
+    pushes all N rows and never reads the stale ones): visit distributions, counters and nn_evals (the reference's row
+    count) are identical with the compaction on and off, only nn_rows (rows really evaluated) differs"""
+    import diee_amd
+    walk = oracle.random_walk_states(55, 60)
+    late = walk[walk["off"].max(axis=1) >= 11]            # bear-off positions: terminal leaves within a few plies
+    states = np.concatenate([late[:200], walk[100:100 + 3 * 400:3]])
+    n = len(states)
+    assert n == 600
+    _, gcfg = cfgs(oracle, 12)
+    gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
+    res = []
+    for compact in ("1", "0"):
+        monkeypatch.setenv("DIEE_COMPACT", compact)
+        e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+        res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 4, gids, rds, ref_quirks=True))
+        e.close()
+    a, b = res
+    assert a["probs"].tobytes() == b["probs"].tobytes() and (a["root_visits"] == b["root_visits"]).all()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert a["stats"][key] == b["stats"][key], key
+    assert b["stats"]["nn_rows"] == b["stats"]["nn_evals"] == 13 * n
+    assert a["stats"]["terminal_hits"] > 0
+    assert a["stats"]["nn_rows"] == a["stats"]["nn_evals"] - a["stats"]["terminal_hits"]      # one row saved per terminal selection
