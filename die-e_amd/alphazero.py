@@ -100,8 +100,14 @@ def make_resnet():
             self.p_conv = nn.Conv2d(F, 32, 3, padding=1); self.p_bn = nn.BatchNorm2d(32); self.p_fc = nn.Linear(768, A)
             self.v_conv = nn.Conv2d(F, 3, 3, padding=1); self.v_bn = nn.BatchNorm2d(3); self.v_fc = nn.Linear(72, 1)
 
+        engine_tower = False        # True: the 38 tower convolutions and their BatchNorm + ReLU run on the engine's own
+                                    # kernels in the bf16 token layout (die-e_amd/train_ops.py); needs CUDA tensors
+
         def forward_train(self, x):
             """raw policy logits + tanh value (nnet.rs:137-148; the value head's tanh is inside the head)"""
+            if self.engine_tower and x.is_cuda and self.training:
+                from . import train_ops
+                return train_ops.forward_train_tokens(self, x)
             x = torch.relu(self.init_bn(self.init_conv(x)))
             for b in self.blocks:
                 x = b(x)
@@ -160,9 +166,15 @@ class AlphaZero:
             dev = torch.device(self.device)
             self.ddp = DDP(self.model, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()]
                            if dev.type == "cuda" else None)
+        on_gpu = torch.device(self.device).type == "cuda"
+        # DIEE_TRAIN=torch: the all-PyTorch fp32 step (MIOpen convolutions); default on a GPU: the tower on the engine's kernels
+        self.model.engine_tower = on_gpu and os.environ.get("DIEE_TRAIN", "engine") != "torch"
+        # the whole step (forward, backward, Adam) replayed as one HIP graph for full batches (single-rank training only)
+        self.use_graph = on_gpu and world == 1 and os.environ.get("DIEE_TRAIN_GRAPH", "1") != "0"
+        self._graph = None
         # Adam::default().wd(op.wd).build(&vs, op.lr), alphazero.rs:102 (L2 added to the gradient, not AdamW)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=op.lr, betas=(0.9, 0.999), eps=1e-8,
-                                          weight_decay=op.wd)
+                                          weight_decay=op.wd, fused=on_gpu, capturable=self.use_graph)
 
     @classmethod
     def from_config(cls, engine, conf, model_path=None, **kw):                   # alphazero.rs:113-127, :81-100
@@ -238,15 +250,93 @@ class AlphaZero:
         return {k: np.concatenate([m[k] for m in mems]) for k in ("outcome", "ps", "state")}
 
     # ---- train, alphazero.rs:202-261 ----
+    def _loss(self, net, st, ps, oc):
+        import torch.nn.functional as Fn
+        logits, value = net(st)
+        policy_loss = Fn.cross_entropy(logits.float(), ps)                      # soft targets = un-renormalised ps (Q17), :239-245
+        outcome_loss = Fn.mse_loss(value.float(), oc)                           # :246
+        return policy_loss + outcome_loss
+
+    def _snapshot(self):
+        import torch
+        return ({k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()})
+
+    def _restore(self, snap):
+        """put parameters, BatchNorm statistics and Adam's state back IN PLACE (same tensors, same addresses)"""
+        import torch
+        model_snap, opt_snap = snap
+        self.model.load_state_dict(model_snap)                                  # copies into the existing tensors
+        for p, st in self.optimizer.state.items():
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if p in opt_snap and k in opt_snap[p]:
+                        v.copy_(opt_snap[p][k])
+                    else:
+                        v.zero_()                                               # state born during a warm-up: Adam starts from zero moments, step 0
+
+    def _graph_selfcheck(self, g, st, ps, oc):
+        """One replay on a real batch, checked against the eager loss of the same batch, then undone.  On this ROCm stack
+        the first replays after a fresh large hipMalloc have been seen to compute a zero policy loss (all-PyTorch steps
+        too) until the device was synchronised behind one of them; the training buffers are therefore allocated before the
+        capture, and this check makes sure of the graph at the start of every train() call.  False = fall back to eager."""
+        import torch
+        for _ in range(3):
+            snap = self._snapshot()
+            g["st"].copy_(st); g["ps"].copy_(ps); g["oc"].copy_(oc)
+            torch.cuda.synchronize()
+            g["graph"].replay()
+            torch.cuda.synchronize()
+            got = float(g["loss"].detach())
+            self._restore(snap)
+            with torch.no_grad():
+                want = float(self._loss(self.model, g["st"], g["ps"], g["oc"]))
+            self._restore(snap)                                                 # the eager forward moved the BatchNorm statistics
+            torch.cuda.synchronize()
+            if np.isfinite(got) and abs(got - want) <= 2e-2 * max(1.0, abs(want)):
+                return True
+        return False
+
+    def _graphed_step(self, bs):
+        """forward + backward + Adam of one full batch captured once as a HIP graph (static input tensors; every kernel of
+        the step, the engine's included, goes out on the capturing stream): a replay costs one launch instead of ~1500"""
+        import torch
+        if self._graph is not None and self._graph["bs"] == bs:
+            return self._graph
+        g = {"bs": bs, "st": torch.zeros(bs, 6, 4, 6, device=self.device), "ps": torch.zeros(bs, BG_ACTIONS, device=self.device),
+             "oc": torch.zeros(bs, 1, device=self.device)}
+        g["ps"][:, 0] = 1.0
+        # warm-up and capture run real steps: parameters, BatchNorm statistics and Adam's moments are put back afterwards,
+        # IN PLACE (the captured graph holds the addresses of these very tensors)
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                                                  # allocator / autotune warm-up outside the capture
+                self.optimizer.zero_grad(set_to_none=True)
+                self._loss(self.model, g["st"], g["ps"], g["oc"]).backward()
+                self.optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        # no .grad tensors going in: the captured backward then WRITES its gradients (into graph-pool memory the captured Adam
+        # reads) instead of accumulating into zero-filled ones -- 250 fills and 250 adds per step less
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss = self._loss(self.model, g["st"], g["ps"], g["oc"])
+            loss.backward()
+            self.optimizer.step()
+        g["graph"], g["loss"] = graph, loss
+        self._restore(snap)
+        self._graph = g
+        return g
+
     def train(self, memory, rng=None):
         import torch
-        import torch.nn.functional as Fn
         n = len(memory["outcome"])
         rng = rng or self.shuffle_rng                                           # a fresh permutation every call (every epoch)
         perm = rng.permutation(n)                                               # memory.shuffle(&mut rng), :203-204
         net = self.ddp or self.model
         net.train()                                                             # forward_train(.., true): BN batch statistics
-        losses = []
         bs = self.config.training_batch_size
         n_steps = -(-n // bs)
         if self.ddp is not None:
@@ -257,21 +347,59 @@ class AlphaZero:
             t = torch.tensor([n_steps], dtype=torch.int64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             n_steps = int(t.item())
-        for b0 in range(0, n_steps * bs, bs):                                   # :205-206
-            idx = perm[b0:b0 + bs]
-            st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6).to(self.device)
-            ps = torch.from_numpy(memory["ps"][idx]).to(self.device)
-            oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1).to(self.device)
-            logits, value = net(st)
-            policy_loss = Fn.cross_entropy(logits, ps)                          # soft targets = un-renormalised ps (Q17), :239-245
-            outcome_loss = Fn.mse_loss(value, oc)                               # :246
-            loss = policy_loss + outcome_loss
-            if not torch.isfinite(loss):
-                raise FloatingPointError("Total loss is nan or inf!")          # :248-255
-            self.optimizer.zero_grad()
-            loss.backward()
-            self.optimizer.step()
-            losses.append(float(loss.detach()))
+        on_gpu = torch.device(self.device).type == "cuda"
+        if on_gpu:
+            # The whole memory goes to HBM once (0.44 M fragments = 2.6 GB), into buffers that persist across calls and only
+            # grow.  Growing them drops the captured graph first: on this ROCm stack the replays that follow a fresh
+            # hipMalloc of a large block compute garbage until the device has been synchronised after one of them
+            # (observed: the policy loss of the first replays reads 0; an all-PyTorch step under torch.cuda.graph shows the
+            # same), so the step is captured only after every large allocation of the call exists.
+            cap = getattr(self, "_mem_cap", 0)
+            if n > cap:
+                self._graph = None
+                cap = max(1 << 14, 1 << int(np.ceil(np.log2(n))))
+                self._mem = None
+                torch.cuda.empty_cache()
+                self._mem = {"st": torch.empty(cap, BG_PLANES, device=self.device), "ps": torch.empty(cap, BG_ACTIONS, device=self.device),
+                             "oc": torch.empty(cap, device=self.device), "perm": torch.empty(cap, dtype=torch.int64, device=self.device),
+                             "loss": torch.zeros(-(-cap // max(bs, 1)) + 1, device=self.device)}
+                self._mem_cap = cap
+                torch.cuda.synchronize()
+            M = self._mem
+            M["st"][:n].copy_(torch.from_numpy(memory["state"])); M["ps"][:n].copy_(torch.from_numpy(memory["ps"]))
+            M["oc"][:n].copy_(torch.from_numpy(memory["outcome"].astype(np.float32))); M["perm"][:n].copy_(torch.from_numpy(perm))
+            mem_st, mem_ps, mem_oc, perm_t = M["st"], M["ps"], M["oc"], M["perm"]
+            loss_buf = M["loss"] if len(M["loss"]) >= n_steps else torch.zeros(max(n_steps, 1), device=self.device)
+        else:
+            loss_buf = torch.zeros(max(n_steps, 1))                            # read back once: no host sync per step
+        use_graph = self.use_graph and n >= bs
+        if use_graph:
+            g = self._graphed_step(bs)
+            i0 = perm_t[:bs]
+            if not self._graph_selfcheck(g, mem_st[i0].reshape(-1, 6, 4, 6), mem_ps[i0], mem_oc[i0].unsqueeze(1)):
+                self.log("[train] the captured step does not reproduce the eager loss: training eagerly")
+                use_graph = False
+        for i, b0 in enumerate(range(0, n_steps * bs, bs)):                     # :205-206
+            if on_gpu:
+                idx = perm_t[b0:min(b0 + bs, n)]
+                st = mem_st[idx].reshape(-1, 6, 4, 6); ps = mem_ps[idx]; oc = mem_oc[idx].unsqueeze(1)
+            else:
+                idx = perm[b0:b0 + bs]
+                st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6)
+                ps = torch.from_numpy(memory["ps"][idx]); oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1)
+            if use_graph and len(idx) == bs:
+                g["st"].copy_(st); g["ps"].copy_(ps); g["oc"].copy_(oc)
+                g["graph"].replay()
+                loss_buf[i] = g["loss"].detach()
+            else:
+                loss = self._loss(net, st, ps, oc)
+                self.optimizer.zero_grad(set_to_none=True)                      # (the captured step keeps its own gradient tensors)
+                loss.backward()
+                self.optimizer.step()
+                loss_buf[i] = loss.detach()
+        losses = loss_buf[:n_steps].tolist()
+        if not np.isfinite(losses).all():
+            raise FloatingPointError("Total loss is nan or inf!")              # :248-255
         return losses
 
     def sync_engine(self):

@@ -3,6 +3,7 @@
 #include "../../include/diee_dev.h"
 #include "engine.h"
 #include "nn_host.h"
+#include "launch.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -202,6 +203,53 @@ diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint3
     if (!states || !n || reps <= 0 || !us_legal_moves || !mean_plays) throw EngineError(DIEE_ERR_ARG, "bad arguments");
     c->rules_bench(states, n, reps, us_legal_moves, mean_plays);
     API_END(c)
+}
+
+// ---- training-step kernels: stateless, on the caller's stream ----
+static const float* zero_bias256() {
+    static float* z = nullptr;                                   // one 1 KB allocation per process and device use is enough here
+    if (!z) { if (hipMalloc((void**)&z, 256 * sizeof(float)) != hipSuccess) return nullptr; (void)hipMemset(z, 0, 256 * sizeof(float)); }
+    return z;
+}
+diee_status diee_train_pack_conv3x3(const float* w, void* wpack, int transpose, void* stream) {
+    if (!w || !wpack) return DIEE_ERR_ARG;
+    launch_pack_conv_w((hipStream_t)stream, w, (uint16_t*)wpack, transpose);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
+diee_status diee_train_conv3x3(const void* x, const void* wpack, const float* bias, void* y, int boards, void* stream) {
+    if (!x || !wpack || !y || boards <= 0) return DIEE_ERR_ARG;
+    if (!bias) bias = zero_bias256();
+    if (!bias) return DIEE_ERR_HIP;
+    launch_conv3x3((hipStream_t)stream, 256, 3, (const uint16_t*)x, wpack, bias, nullptr, (uint16_t*)y, nullptr, boards, 256);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
+diee_status diee_train_im2col3x3(const void* x, void* col, int boards, void* stream) {
+    if (!x || !col || boards <= 0) return DIEE_ERR_ARG;
+    launch_im2col3x3((hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, boards);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
+
+size_t diee_train_scratch_floats(int rows) { return (size_t)train_stripes(rows) * 512 + 1280; }   // partials + the apply pass's coefficients
+diee_status diee_train_bn_relu_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* run_mean,
+                                   float* run_var, float momentum, float eps, float* save_mean, float* save_invstd, void* y, int rows,
+                                   float* scratch, void* stream) {
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch || rows <= 0) return DIEE_ERR_ARG;
+    launch_bn_relu_fwd((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)res, gamma, beta, scratch, save_mean, save_invstd,
+                       run_mean, run_var, momentum, eps, (uint16_t*)y, rows);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
+diee_status diee_train_bn_relu_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                                   const float* save_invstd, float* dgamma, float* dbeta, void* dx, void* dres, int rows,
+                                   float* scratch, void* stream) {
+    if (!dy || !y || !x || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dx || !scratch || rows <= 0) return DIEE_ERR_ARG;
+    launch_bn_relu_bwd((hipStream_t)stream, (const uint16_t*)dy, (const uint16_t*)y, (const uint16_t*)x, gamma, save_mean, save_invstd,
+                       scratch, dgamma, dbeta, (uint16_t*)dx, (uint16_t*)dres, rows);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
+diee_status diee_train_colsum(const void* a, float* out, int rows, float* scratch, void* stream) {
+    if (!a || !out || !scratch || rows <= 0) return DIEE_ERR_ARG;
+    launch_colsum((hipStream_t)stream, (const uint16_t*)a, scratch, out, rows);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
 
 void diee_free_fragments(diee_fragments* f) {

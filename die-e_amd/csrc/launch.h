@@ -37,6 +37,17 @@ constexpr int kClusterMaxGroups = 64;
 // `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
+// train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 512 floats of scratch)
+int train_stripes(int M);
+void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,
+                        float* save_mean, float* save_invstd, float* run_mean, float* run_var, float momentum, float eps,
+                        uint16_t* y, int M);
+void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
+                        const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
+                        uint16_t* dres, int M);
+void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);
+void launch_pack_conv_w(hipStream_t st, const float* w_oihw, uint16_t* wpack, int transpose);
+void launch_im2col3x3(hipStream_t st, const uint16_t* x, uint16_t* col, int boards);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G,
                       const uint32_t* n_rows = nullptr);   // n_rows non-null: device-side row count of a compacted batch (<= G)
 // fused tower over a batch compacted on the device: row_slot[row] = slot to evaluate, *n_rows rows (<= n_upper); see RowMap

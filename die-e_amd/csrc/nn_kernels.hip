@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3(const uint16_t* __restrict_
         u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float x0 = v[2 * j] > 0.0f ? v[2 * j] : 0.0f, x1 = v[2 * j + 1] > 0.0f ? v[2 * j + 1] : 0.0f;
+            // MODE 3 (training: the raw convolution, BatchNorm follows in train mode) keeps the sign
+            const float x0 = (MODE == 3 || v[2 * j] > 0.0f) ? v[2 * j] : 0.0f, x1 = (MODE == 3 || v[2 * j + 1] > 0.0f) ? v[2 * j + 1] : 0.0f;
             o[j] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
             v[2 * j] = x0; v[2 * j + 1] = x1;
         }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_conv3x3_sk(const uint16_t* __re
         u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float x0 = v[2 * j] > 0.0f ? v[2 * j] : 0.0f, x1 = v[2 * j + 1] > 0.0f ? v[2 * j + 1] : 0.0f;
+            const float x0 = (MODE == 3 || v[2 * j] > 0.0f) ? v[2 * j] : 0.0f, x1 = (MODE == 3 || v[2 * j + 1] > 0.0f) ? v[2 * j + 1] : 0.0f;
             o[j] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
             v[2 * j] = x0; v[2 * j + 1] = x1;
         }
@@ -1645,8 +1646,40 @@ void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, con
     }
     else if (mode == 0) conv256_dispatch<0>(st, act, wpack, bias, res, out, out_v, G, N);
     else if (mode == 1) conv256_dispatch<1>(st, act, wpack, bias, res, out, out_v, G, N);
+    else if (mode == 3) conv256_dispatch<3>(st, act, wpack, bias, res, out, out_v, G, N);   // raw conv + bias (training)
     else if (G > 96) conv_sk_launch<2, 4>(st, act, wpack, bias, res, out, G, N, out_v);  // heads: N = 64 (35 real), split-K
     else conv_sk_launch<2, 2>(st, act, wpack, bias, res, out, G, N, out_v);
+}
+
+// ---- training-step helpers (die-e_amd/train_ops.py): the tower convolutions of the learn loop's training step run on the
+// inference conv kernel (MODE 3 = raw conv + bias) for the forward pass and, with the weights transposed and flipped,
+// for the input gradient; the weight gradient is col^T x dY with col = im2col of the saved input.
+// fp32 OIHW [256][256][3][3] -> bf16 B fragments [n/32][cs*9 + tap][lane][8] of k_conv3x3 (pack_conv on the host);
+// transpose: the fragments of W'[c][n][2-ky][2-kx] (the convolution that maps dY to dX)
+__global__ void k_pack_conv_w(const float* __restrict__ w, uint16_t* __restrict__ out, int transpose) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;           // one thread per fragment element
+    if (i >= 8 * 144 * 64 * 8) return;
+    const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 144, s = i / (144 * 512);
+    const int n = s * 32 + (lane & 31), c = (ks / 9) * 16 + 8 * (lane >> 5) + j, t = ks % 9;
+    const float v = transpose ? w[((size_t)c * 256 + n) * 9 + (8 - t)] : w[((size_t)n * 256 + c) * 9 + t];
+    out[i] = f2bf(v);
+}
+// col[row][t*256 + c] = x[row + 6*dy + dx][c] inside the board, 0 outside (16 bytes per thread)
+__global__ void k_im2col3x3(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int M) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * 9 * 32) return;
+    const int ch = (int)(i & 31), t = (int)((i >> 5) % 9), row = (int)(i / (9 * 32));
+    const int p = row % 24, y = p / 6, xx = p % 6, dy = t / 3 - 1, dx = t % 3 - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned)(y + dy) < 4u && (unsigned)(xx + dx) < 6u) v = *(const u32x4*)(x + (size_t)(row + 6 * dy + dx) * 256 + ch * 8);
+    *(u32x4*)(col + (size_t)row * 2304 + t * 256 + ch * 8) = v;
+}
+void launch_pack_conv_w(hipStream_t st, const float* w, uint16_t* out, int transpose) {
+    hipLaunchKernelGGL(k_pack_conv_w, dim3(8 * 144 * 64 * 8 / 256), dim3(256), 0, st, w, out, transpose);
+}
+void launch_im2col3x3(hipStream_t st, const uint16_t* x, uint16_t* col, int boards) {
+    const size_t n = (size_t)boards * 24 * 9 * 32;
+    hipLaunchKernelGGL(k_im2col3x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, col, boards * 24);
 }
 
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G,

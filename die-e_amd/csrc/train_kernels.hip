@@ -1,0 +1,220 @@
+// train_kernels.hip -- memory-bound kernels of the learn loop's training step in the NHWC token layout
+// x[row = board*24 + point][256] bf16: BatchNorm in train mode fused with the residual add and the ReLU
+// (ResBlock::forward_t, src/alphazero/nnet.rs:24-34, with `train = true`: batch statistics over batch x 4 x 6), its
+// backward, and a column sum (the convolution's bias gradient).  PyTorch's own batch-norm kernels take 33 us per pass on
+// this shape (a [6144, 256] bf16 matrix, 3 MB: profiles/r02_train_step_engine_kernel_stats*.csv); these take one
+// 3 MB sweep each.  Reductions are two-stage (per-stripe partials, then every workgroup folds the partials in a fixed
+// order): deterministic, no atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+
+namespace diee {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t tu32x4;
+
+__device__ __forceinline__ float tbf2f(uint32_t b16) { return __uint_as_float(b16 << 16); }
+__device__ __forceinline__ uint16_t tf2bf(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
+__device__ __forceinline__ void unpack8(const tu32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = tbf2f(v[j] & 0xffffu); f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ tu32x4 pack8(const float (&f)[8]) {
+    tu32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)tf2bf(f[2 * j]) | ((uint32_t)tf2bf(f[2 * j + 1]) << 16);
+    return o;
+}
+
+constexpr int kStripe = 64;             // rows per workgroup: 96 workgroups at 256 boards
+// thread t of a 256-thread workgroup: channels 8*(t & 31) .. +8, rows (t >> 5) + 8*k of the stripe
+
+// partial[stripe][q][256]: q = 0 sum of a, 1 sum of a*b  (b == nullptr: a*a), optionally with a masked by mask > 0 and
+// b normalised as (b - mean) * invstd
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_col_partials(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                      const uint16_t* __restrict__ mask, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, float* __restrict__ partial, int M) {
+    __shared__ float red[2][8][256];
+    const int t = threadIdx.x, c8 = t & 31, r0 = t >> 5;
+    const int row_lo = blockIdx.x * kStripe;
+    float s0[8], s1[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mu[j] = 0.f; is[j] = 1.f; }
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mu[j] = mean[c8 * 8 + j]; is[j] = invstd[c8 * 8 + j]; }
+    }
+    for (int r = row_lo + r0; r < row_lo + kStripe && r < M; r += 8) {
+        float av[8], bv[8];
+        unpack8(*(const tu32x4*)(a + (size_t)r * 256 + c8 * 8), av);
+        if (BWD) {
+            float mv[8];
+            unpack8(*(const tu32x4*)(mask + (size_t)r * 256 + c8 * 8), mv);
+            unpack8(*(const tu32x4*)(b + (size_t)r * 256 + c8 * 8), bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dz = mv[j] > 0.f ? av[j] : 0.f;
+                s0[j] += dz; s1[j] += dz * ((bv[j] - mu[j]) * is[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] += av[j]; s1[j] += av[j] * av[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][r0][c8 * 8 + j] = s0[j]; red[1][r0][c8 * 8 + j] = s1[j]; }
+    __syncthreads();
+    float x0 = 0.f, x1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { x0 += red[0][k][t]; x1 += red[1][k][t]; }
+    partial[((size_t)blockIdx.x * 2 + 0) * 256 + t] = x0;
+    partial[((size_t)blockIdx.x * 2 + 1) * 256 + t] = x1;
+}
+
+// fold the stripes' partials: ONE workgroup of 1024 threads = 4 parts x 256 channels; a part folds its quarter of the
+// stripes with two interleaved accumulators, the parts are combined through LDS in a fixed order (deterministic).
+// Every thread returns the totals of channel (threadIdx.x & 255).
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int stripes, float& q0, float& q1) {
+    __shared__ float acc[2][4][256];
+    const int c = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const int per = (stripes + 3) / 4, s0 = part * per, s1 = s0 + per < stripes ? s0 + per : stripes;
+    float a[2] = {0.f, 0.f}, b[2] = {0.f, 0.f};
+    int s = s0;
+    for (; s + 2 <= s1; s += 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a[k] += partial[((size_t)(s + k) * 2 + 0) * 256 + c];
+            b[k] += partial[((size_t)(s + k) * 2 + 1) * 256 + c];
+        }
+    }
+    if (s < s1) { a[0] += partial[((size_t)s * 2 + 0) * 256 + c]; b[0] += partial[((size_t)s * 2 + 1) * 256 + c]; }
+    acc[0][part][c] = a[0] + a[1]; acc[1][part][c] = b[0] + b[1];
+    __syncthreads();
+    q0 = (acc[0][0][c] + acc[0][1][c]) + (acc[0][2][c] + acc[0][3][c]);
+    q1 = (acc[1][0][c] + acc[1][1][c]) + (acc[1][2][c] + acc[1][3][c]);
+}
+
+// forward finalisation: mean / invstd, running statistics (momentum, unbiased variance, like torch.nn.BatchNorm2d.train()),
+// and the affine map of the apply pass: coef[0][c] = gamma * invstd, coef[1][c] = beta - mean * gamma * invstd
+__global__ __launch_bounds__(1024) void k_bn_stats(const float* __restrict__ partial, int stripes, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                  float* __restrict__ save_invstd, float* __restrict__ run_mean,
+                                                  float* __restrict__ run_var, float momentum, float eps, float* __restrict__ coef, int M) {
+    const int t = threadIdx.x & 255;
+    float s, ss;
+    fold_partials(partial, stripes, s, ss);
+    if (threadIdx.x >= 256) return;
+    const float mean = s / (float)M;
+    float var = ss / (float)M - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float is = 1.0f / sqrtf(var + eps);
+    coef[t] = gamma[t] * is; coef[256 + t] = beta[t] - mean * gamma[t] * is;
+    save_mean[t] = mean; save_invstd[t] = is;
+    if (run_mean) {
+        const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+        run_mean[t] = (1.f - momentum) * run_mean[t] + momentum * mean;
+        run_var[t] = (1.f - momentum) * run_var[t] + momentum * unb;
+    }
+}
+
+// y = relu(x * coef0 + coef1 [+ res])
+__global__ __launch_bounds__(256) void k_bn_relu_fwd(const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+                                                     const float* __restrict__ coef, uint16_t* __restrict__ y, int M) {
+    const int t = threadIdx.x, c8 = t & 31, r0 = t >> 5;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = coef[c8 * 8 + j]; sh[j] = coef[256 + c8 * 8 + j]; }
+    const int row_lo = blockIdx.x * kStripe;
+    for (int r = row_lo + r0; r < row_lo + kStripe && r < M; r += 8) {
+        float v[8], rv[8];
+        unpack8(*(const tu32x4*)(x + (size_t)r * 256 + c8 * 8), v);
+        if (res) unpack8(*(const tu32x4*)(res + (size_t)r * 256 + c8 * 8), rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            if (res) z += rv[j];
+            v[j] = z > 0.f ? z : 0.f;
+        }
+        *(tu32x4*)(y + (size_t)r * 256 + c8 * 8) = pack8(v);
+    }
+}
+
+// backward finalisation: dgamma = sum dz * xhat, dbeta = sum dz, and the coefficients of the apply pass:
+// coef[0] = gamma * invstd, [1] = mean(dz), [2] = mean(dz * xhat), [3] = mean, [4] = invstd
+__global__ __launch_bounds__(1024) void k_bn_bwd_stats(const float* __restrict__ partial, int stripes, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int M) {
+    const int t = threadIdx.x & 255;
+    float sdz, sdzx;
+    fold_partials(partial, stripes, sdz, sdzx);
+    if (threadIdx.x >= 256) return;
+    dgamma[t] = sdzx; dbeta[t] = sdz;
+    coef[t] = gamma[t] * invstd[t]; coef[256 + t] = sdz / (float)M; coef[512 + t] = sdzx / (float)M;
+    coef[768 + t] = mean[t]; coef[1024 + t] = invstd[t];
+}
+
+// dz = dy * (y > 0); dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); dres = dz
+__global__ __launch_bounds__(256) void k_bn_relu_bwd(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ y,
+                                                     const uint16_t* __restrict__ x, const float* __restrict__ coef,
+                                                     uint16_t* __restrict__ dx, uint16_t* __restrict__ dres, int M) {
+    const int t = threadIdx.x, c8 = t & 31, r0 = t >> 5;
+    float k0[8], k1[8], k2[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        k0[j] = coef[c]; k1[j] = coef[256 + c]; k2[j] = coef[512 + c]; mu[j] = coef[768 + c]; is[j] = coef[1024 + c];
+    }
+    const int row_lo = blockIdx.x * kStripe;
+    for (int r = row_lo + r0; r < row_lo + kStripe && r < M; r += 8) {
+        float g[8], yv[8], xv[8], dz[8];
+        unpack8(*(const tu32x4*)(dy + (size_t)r * 256 + c8 * 8), g);
+        unpack8(*(const tu32x4*)(y + (size_t)r * 256 + c8 * 8), yv);
+        unpack8(*(const tu32x4*)(x + (size_t)r * 256 + c8 * 8), xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dz[j] = yv[j] > 0.f ? g[j] : 0.f;
+            const float xh = (xv[j] - mu[j]) * is[j];
+            g[j] = k0[j] * (dz[j] - k1[j] - xh * k2[j]);
+        }
+        *(tu32x4*)(dx + (size_t)r * 256 + c8 * 8) = pack8(g);
+        if (dres) *(tu32x4*)(dres + (size_t)r * 256 + c8 * 8) = pack8(dz);
+    }
+}
+
+// out[c] = sum over rows of a[row][c] (fp32), from the partials of k_col_partials<false>
+__global__ __launch_bounds__(1024) void k_colsum_final(const float* __restrict__ partial, int stripes, float* __restrict__ out) {
+    float s, ss;
+    fold_partials(partial, stripes, s, ss);
+    if (threadIdx.x < 256) out[threadIdx.x] = s;
+}
+
+int train_stripes(int M) { return (M + kStripe - 1) / kStripe; }
+
+void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,
+                        float* save_mean, float* save_invstd, float* run_mean, float* run_var, float momentum, float eps,
+                        uint16_t* y, int M) {
+    const int S = train_stripes(M);
+    float* coef = partial + (size_t)S * 512;
+    hipLaunchKernelGGL((k_col_partials<false>), dim3(S), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, partial, M);
+    hipLaunchKernelGGL(k_bn_stats, dim3(1), dim3(1024), 0, st, partial, S, gamma, beta, save_mean, save_invstd, run_mean, run_var,
+                       momentum, eps, coef, M);
+    hipLaunchKernelGGL(k_bn_relu_fwd, dim3(S), dim3(256), 0, st, x, res, coef, y, M);
+}
+void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
+                        const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
+                        uint16_t* dres, int M) {
+    const int S = train_stripes(M);
+    float* coef = partial + (size_t)S * 512;
+    hipLaunchKernelGGL((k_col_partials<true>), dim3(S), dim3(256), 0, st, dy, x, y, mean, invstd, partial, M);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(1), dim3(1024), 0, st, partial, S, gamma, mean, invstd, dgamma, dbeta, coef, M);
+    hipLaunchKernelGGL(k_bn_relu_bwd, dim3(S), dim3(256), 0, st, dy, y, x, coef, dx, dres, M);
+}
+void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M) {
+    const int S = train_stripes(M);
+    hipLaunchKernelGGL((k_col_partials<false>), dim3(S), dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, partial, M);
+    hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(1024), 0, st, partial, S, out);
+}
+
+}  // namespace diee

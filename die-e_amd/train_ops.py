@@ -1,0 +1,156 @@
+"""The tower convolutions of the learn loop's training step on the engine's own MFMA kernels.
+
+AlphaZero::train (src/alphazero/alphazero.rs:202-261) is tch autograd over libtorch convolutions in the reference; on
+MI355X the PyTorch-ROCm step spends ~100 us per convolution call in MIOpen (Winograd forward, implicit-GEMM weight
+gradient, im2col + GEMM data gradient on these 4x6 boards: profiles/r02_train_step_pytorch_kernel_stats.csv) -- 12-17 ms
+per 256-sample step, 2.7 % of the bf16 peak, two thirds of the learn loop.  Here the 38 convolutions of the tower run
+
+    forward   y  = conv3x3(x, W) + b           the inference kernel k_conv3x3 / k_conv3x3_sk, raw output (MODE 3)
+    dgrad     dx = conv3x3(dy, W^T flipped)     the same kernel on re-packed weights
+    wgrad     dW = im2col(x)^T @ dy             hand-written gather + the framework's bf16 GEMM (hipBLASLt / rocBLAS)
+
+in the NHWC token layout [batch*24, 256] bf16 (fp32 master weights, bf16 operands, fp32 accumulation: ordinary mixed
+precision), and BatchNorm in train mode + residual add + ReLU of every ResBlock is one fused pass forward and one
+backward (PyTorch's batch-norm kernels take 33 us per pass on a [6144, 256] matrix; these take a 3 MB sweep).  The init
+block, the heads, the losses and Adam stay PyTorch.  Gradients are checked against fp32 autograd in tests/test_train_gpu.py.
+"""
+import ctypes as C
+
+import torch
+
+from . import load_library
+
+_N_PACK = 8 * 144 * 64 * 8          # bf16 elements of one packed 256x256x3x3 convolution
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(st, what):
+    if st != 0:
+        raise RuntimeError(f"{what} failed with diee status {st}")
+
+
+class Conv3x3Tok(torch.autograd.Function):
+    """y[M,256] = conv3x3 over 4x6 boards of x[M,256] (M = boards*24, bf16) with w[256,256,3,3] (fp32) + b[256] (fp32)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        L = load_library()
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 256 and x.shape[0] % 24 == 0
+        assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (256, 256, 3, 3)
+        boards = x.shape[0] // 24
+        wp = torch.empty(_N_PACK, dtype=torch.bfloat16, device=x.device)
+        _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(wp), 0, _stream()), "pack")
+        y = torch.empty_like(x)
+        bias = b.detach().float().contiguous()
+        _chk(L.diee_train_conv3x3(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), boards, _stream()), "conv3x3 forward")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = load_library()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        boards = x.shape[0] // 24
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = torch.empty(_N_PACK, dtype=torch.bfloat16, device=x.device)
+            _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(wp), 1, _stream()), "pack (transposed)")
+            dx = torch.empty_like(x)
+            _chk(L.diee_train_conv3x3(_ptr(dy), _ptr(wp), None, _ptr(dx), boards, _stream()), "conv3x3 dgrad")
+        if ctx.needs_input_grad[1]:
+            col = torch.empty(x.shape[0], 2304, dtype=torch.bfloat16, device=x.device)
+            _chk(L.diee_train_im2col3x3(_ptr(x), _ptr(col), boards, _stream()), "im2col")
+            dwf = torch.matmul(col.t(), dy)                      # [2304 = t*256 + c, 256 = n], fp32 accumulation inside
+            dw = dwf.float().view(3, 3, 256, 256).permute(3, 2, 0, 1).contiguous()      # -> [n][c][ky][kx]
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(256, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(int(L.diee_train_scratch_floats(x.shape[0])), dtype=torch.float32, device=x.device)
+            _chk(L.diee_train_colsum(_ptr(dy), _ptr(db), x.shape[0], _ptr(scratch), _stream()), "colsum")
+        return dx, dw, db
+
+
+class BnReluTok(torch.autograd.Function):
+    """y = relu(batch_norm_train(x; gamma, beta) [+ res]) over the rows of x[M,256] bf16; updates running_mean / running_var
+    in place (momentum, unbiased variance) like torch.nn.BatchNorm2d.train()"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, momentum, eps):
+        L = load_library()
+        assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 256
+        M = x.shape[0]
+        y = torch.empty_like(x)
+        mean = torch.empty(256, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
+        scratch = torch.empty(int(L.diee_train_scratch_floats(M)), dtype=torch.float32, device=x.device)
+        if res is not None:
+            res = res.contiguous()
+        _chk(L.diee_train_bn_relu_fwd(_ptr(x), _ptr(res) if res is not None else None, _ptr(gamma), _ptr(beta),
+                                      _ptr(running_mean) if running_mean is not None else None,
+                                      _ptr(running_var) if running_var is not None else None, float(momentum), float(eps),
+                                      _ptr(mean), _ptr(invstd), _ptr(y), M, _ptr(scratch), _stream()), "bn_relu forward")
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = load_library()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        M = x.shape[0]
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty(256, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+        scratch = torch.empty(int(L.diee_train_scratch_floats(M)), dtype=torch.float32, device=x.device)
+        _chk(L.diee_train_bn_relu_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
+                                      _ptr(dx), _ptr(dres) if dres is not None else None, M, _ptr(scratch), _stream()), "bn_relu backward")
+        return dx, dgamma, dbeta, dres, None, None, None, None
+
+
+def bn_relu_tok(bn, x, res=None):
+    return BnReluTok.apply(x, bn.weight, bn.bias, res, bn.running_mean if bn.training else None,
+                           bn.running_var if bn.training else None, bn.momentum, bn.eps)
+
+
+def conv3x3_tok(x, conv):
+    return Conv3x3Tok.apply(x, conv.weight, conv.bias)
+
+
+def to_tokens(h):
+    """[B,256,4,6] -> [B*24,256] bf16 (row = board*24 + 6*y + x)"""
+    return h.permute(0, 2, 3, 1).reshape(-1, h.shape[1]).to(torch.bfloat16).contiguous()
+
+
+def from_tokens(t, batch):
+    """[B*24,256] -> [B,256,4,6] fp32"""
+    return t.view(batch, 4, 6, t.shape[1]).permute(0, 3, 1, 2).float().contiguous()
+
+
+def _bn_tok(bn, t):
+    """BatchNorm2d over (batch, 4, 6) == batch norm of the token matrix over its rows; statistics in fp32"""
+    return torch.nn.functional.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+
+
+def forward_train_tokens(net, x):
+    """ResNet::forward_t(.., train) (nnet.rs:120-148) with the tower on the engine's kernels; `net` is alphazero.make_resnet()"""
+    B = x.shape[0]
+    h = torch.relu(net.init_bn(net.init_conv(x)))
+    t = to_tokens(h)
+    for blk in net.blocks:                                       # ResBlock::forward_t, nnet.rs:24-34
+        g = bn_relu_tok(blk.bn1, conv3x3_tok(t, blk.conv1))
+        t = bn_relu_tok(blk.bn2, conv3x3_tok(g, blk.conv2), res=t)
+    h = from_tokens(t, B)
+    logits = net.p_fc(torch.relu(net.p_bn(net.p_conv(h))).flatten(1))
+    value = torch.tanh(net.v_fc(torch.relu(net.v_bn(net.v_conv(h))).flatten(1)))
+    return logits, value

@@ -181,6 +181,32 @@ diee_status diee_self_play_multi(diee_ctx*, const diee_batch* batches, uint32_t 
                                  const diee_mcts_cfg* cfg, float temperature, uint32_t flags,
                                  uint32_t max_steps, diee_fragments* outs, diee_stats* stats);
 
+/* ---- training-step kernels (no ctx: plain device pointers of the caller's framework, launched on `stream`, a
+ * hipStream_t; NULL = the default stream).  AlphaZero::train (alphazero.rs:202-261) is tch autograd in the reference;
+ * here the 38 tower convolutions of the step run on the engine's MFMA conv kernel in the NHWC token layout
+ * x[board*24 + point][256] bf16 (die-e_amd/train_ops.py wraps these in a torch.autograd.Function):
+ *   forward   y = conv3x3(x, W) + b                   diee_train_conv3x3(x, pack(W, 0), b, y)
+ *   dgrad     dx = conv3x3(dy, W'), W' = W transposed and flipped   diee_train_conv3x3(dy, pack(W, 1), NULL, dx)
+ *   wgrad     dW[t*256 + c][n] = col^T x dy, col = diee_train_im2col3x3(x)   (the GEMM is the framework's)  */
+diee_status diee_train_pack_conv3x3(const float* w_oihw /*[256][256][3][3]*/, void* wpack /*589 824 bf16*/, int transpose, void* stream);
+diee_status diee_train_conv3x3(const void* x_bf16, const void* wpack, const float* bias /*[256] or NULL*/, void* y_bf16,
+                               int boards, void* stream);
+diee_status diee_train_im2col3x3(const void* x_bf16, void* col_bf16 /*[boards*24][2304]*/, int boards, void* stream);
+/* BatchNorm2d in training mode over the rows (= batch x 4 x 6) fused with the residual add and the ReLU of
+ * ResBlock::forward_t (nnet.rs:24-34): y = relu(gamma * (x - mean) / sqrt(var + eps) + beta [+ res]); updates the running
+ * statistics (momentum, unbiased variance) when given.  scratch: diee_train_scratch_floats(rows) floats.  Deterministic. */
+size_t      diee_train_scratch_floats(int rows);
+diee_status diee_train_bn_relu_fwd(const void* x_bf16, const void* res_bf16 /*or NULL*/, const float* gamma, const float* beta,
+                                   float* running_mean /*or NULL*/, float* running_var, float momentum, float eps,
+                                   float* save_mean /*[256]*/, float* save_invstd /*[256]*/, void* y_bf16, int rows,
+                                   float* scratch, void* stream);
+/* its backward: dx (to the convolution), dres (= dy masked by the ReLU, to the skip connection; may be NULL), dgamma, dbeta */
+diee_status diee_train_bn_relu_bwd(const void* dy_bf16, const void* y_bf16, const void* x_bf16, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                   void* dx_bf16, void* dres_bf16, int rows, float* scratch, void* stream);
+/* out[c] = sum over rows of a[row][c] (the convolution's bias gradient) */
+diee_status diee_train_colsum(const void* a_bf16, float* out /*[256]*/, int rows, float* scratch, void* stream);
+
 /* ---- pure game functions, batched on the GPU (parity tests; LearnableGame trait, base.rs:8-51)
  * A play is int8 {f1,t1,f2,t2}; unused slots DIEE_NO_MOVE. */
 /* get_valid_moves, backgammon_logic.rs:403-414: plays[n][cap][4], counts[n] (count may exceed cap) */
