@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiee.so")
+LIB_PATH = os.environ.get("DIEE_LIB") or os.path.join(_HERE, "libdiee.so")      # DIEE_LIB: an A/B or diagnostic build (scripts/)
 
 BG_ACTIONS = 1352
 BG_PLANES = 144

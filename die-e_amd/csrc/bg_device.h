@@ -11,8 +11,9 @@
 
 namespace diee {
 
-constexpr int kSeqCap = 1024;    // DFS sequences per state (hard bound 34 roots x 17 children = 578)
-constexpr int kTbl = 2048;       // dedup hash slots
+constexpr int kSeqCap = 640;     // DFS sequences per state (hard bound 34 roots x 17 children = 578; more raises the capacity flag)
+constexpr int kTbl = 1024;       // dedup hash slots (load factor <= 0.56)
+constexpr int kMaxPlays = 256;   // legal plays of one state after dedup (measured maximum 139; more raises the capacity flag)
 constexpr int kNoMove = -2;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
@@ -27,7 +28,8 @@ __device__ __forceinline__ int st_roll(const BgState& s, int i) { return (s.w[7]
 __device__ __forceinline__ int st_player(const BgState& s) { return (int)(int8_t)((s.w[7] >> 16) & 0xff); }
 __device__ __forceinline__ int st_second(const BgState& s) { return (s.w[7] >> 24) & 0xff; }
 
-// per-wave LDS scratch for legal-play enumeration (31.1 KB)
+// per-wave LDS scratch for legal-play enumeration (18.4 KB: with k_expand's 1.5 KB on top, 8 one-wave workgroups share a CU's
+// 160 KB -- at 31 KB it was 5, and above 1280 live games k_expand ran in rounds)
 struct WaveScratch {
     uint64_t keyA[kSeqCap];
     uint64_t keyB[kSeqCap];

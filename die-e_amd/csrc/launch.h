@@ -28,8 +28,6 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
                   const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr);
 bool tower_geometry_has_init(int geometry);   // the fused geometry can run the init block (states != nullptr) and the
                                               // head convs (whead16 != nullptr: hp / hv are written, x_out is not) itself
-void launch_net16(hipStream_t st, int geometry, const void* states, const void* winit, const float* binit, const void* wt,
-                  const float* bt, const void* whead, const float* bhead, uint16_t* hp, float* hv, int G);
 void nn_set_tower_dbg(unsigned long long* p);
 // cluster tower: 38 layers in one launch for small batches; `sync` = kClusterMaxGroups counters 128 B apart (zeroed),
 // `err` gets bit 2 set if a cluster wait timed out.  false = not launched (grid would not be co-resident).

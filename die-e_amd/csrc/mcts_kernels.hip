@@ -152,9 +152,8 @@ __global__ __launch_bounds__(64) void k_select(Tree T, Slots S, Segs G, uint32_t
 // ---- expansion + backpropagation ---------------------------------------------------------------
 struct ExpandScratch {
     WaveScratch ws;
-    float raw[kSeqCap];
-    uint16_t code[kSeqCap];
-    float sum;
+    float raw[kMaxPlays];
+    uint16_t code[kMaxPlays];
 };
 
 // turn_policy_to_probs_tensor (utils.rs:74-84; root: utils.rs:60-72 on the Dirichlet-mixed policy,
@@ -209,7 +208,8 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     const uint32_t m0 = T.meta[base + node];
     if (do_expand && !(m0 & kDrained)) {
         const BgState st = load_state(&T.state[base + node]);
-        const int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
+        int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
+        if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }     // never silent: DIEE_ERR_CAPACITY
         const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
         const float* lrow = S.logits + (size_t)row * 1352;
         float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
@@ -227,13 +227,17 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             sc.raw[j] = p; sc.code[j] = (uint16_t)code;
         }
         __syncthreads();
-        if (lane == 0) {                                     // row sum, sequential in play order
-            float s = 0.0f;
-            for (int j = 0; j < k; ++j) s += sc.raw[j];
-            sc.sum = s;
+        // row sum, sequential in play order (the oracle's order): every lane runs the same chain on values broadcast
+        // from their lanes (k <= 256: four registers per lane) -- no LDS round trip per addend
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[r] = lane + 64 * r < k ? sc.raw[lane + 64 * r] : 0.0f;
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kr = k - 64 * r < 64 ? k - 64 * r : 64;                    // uniform
+            for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[r]), j));
         }
-        __syncthreads();
-        const float sum = sc.sum;
         const uint32_t first = T.used[slot];
         if (first + (uint32_t)k > T.node_cap) {
             if (lane == 0) atomicOr(S.overflow, 2u);

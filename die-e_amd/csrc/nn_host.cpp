@@ -146,7 +146,6 @@ void Engine::load_weights(const float* blob, size_t n) {
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
-    if (const char* v = getenv("DIEE_NET16")) net->net16 = atoi(v) != 0;
     if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
@@ -320,7 +319,6 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     int tgeom = W.tower_geometry_for(G);
     if (tgeom < 0 && fused_family) tgeom = 3;                   // the remainder of a batch above 256 boards: never the split-K family
     static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
-    const bool whole = W.net16 && tgeom >= 3 && tgeom <= 5;       // init block + tower + heads in ONE launch (development)
     // sampled timing of the tower: one HIP-event pair per sampled forward (per-launch pairs cost ~4.6 us each and
     // inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -342,7 +340,7 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (cluster(states_dev)) { kind = 2; done = true; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
-    if (!done && !whole && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
+    if (!done && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
         // large batches: init block + all 38 layers in one launch, activations stay in LDS
         stamp0();
         launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G, states_dev, W.winit16.p, W.bconv[0].p,
@@ -350,12 +348,9 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         done = true; heads_done = W.fused_heads;
     }
     if (!done) {
-        if (!whole) init_block();
+        init_block();
         if (!ev0) stamp0();
-        if (whole) {
-            launch_net16(st, tgeom, states_dev, W.winit16.p, W.bconv[0].p, W.wtower16.p, W.btower.p, W.whead16.p, W.bconv[39].p,
-                         hp, hv, G);
-        } else if (tgeom >= 0) {
+        if (tgeom >= 0) {
             launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G);   // all 38 layers, activations stay in LDS
         } else if (cluster(nullptr)) {
             kind = 2;                                                   // (init block launched separately: DIEE_CLUSTER_INIT=0)
@@ -375,7 +370,7 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         HIPCHK(hipEventRecord(ev1, st));
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, kind, -1});
     }
-    if (!whole && !heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
+    if (!heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
@@ -395,7 +390,7 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     nn_reserve(e, G);
     hipStream_t st = e.stream;
     const int tg = W.tower_geometry_for(G);
-    if (rows && W.compact && !policy_dev && G > W.compact_above && tg >= 2 && W.cluster_init && W.fused_heads && !W.net16) {
+    if (rows && W.compact && !policy_dev && G > W.compact_above && tg >= 2 && W.cluster_init && W.fused_heads) {
         const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
         const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
         W.rows_log.ensure(kRowsLog);

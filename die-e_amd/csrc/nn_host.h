@@ -13,9 +13,6 @@ struct NetWeights {
     DevBuf<uint16_t> wtower16;      // [38][16][72][64][8] bf16: the same weights as 16-column fragments (16x16x32 MFMA)
     DevBuf<float> btower;           // [38][256]
     DevBuf<uint16_t> winit16, whead16;   // init block [16][9][64][8] and head convs [4][72][64][8] as 16-column fragments
-    bool net16 = false;             // DIEE_NET16=1: fused geometries 3..5 also run the init block and the head convs in the
-                                    // same launch (k_net16).  Measured null (+-1 %): the two small launches it removes overlap
-                                    // with their neighbours anyway, the in-kernel head conv runs on 3 of the waves only.
     uint16_t* wl(int layer) { return (layer >= 1 && layer <= 38) ? wtower.p + (size_t)(layer - 1) * 8 * 144 * 64 * 8 : wconv[layer].p; }
     float* bl(int layer) { return (layer >= 1 && layer <= 38) ? btower.p + (size_t)(layer - 1) * 256 : bconv[layer].p; }
     // fused-tower dispatch: the first entry with G > min_games wins; batches below every entry run per-layer kernels.

@@ -1205,168 +1205,6 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
     }
 }
 
-// ---- the whole convolutional network in one launch: init block + 38-layer tower + both head convs ----------
-// Same tiles and layer routine as k_tower16; the init block builds the as_tensor planes from the 32-byte states
-// straight into an LDS tile (6 real channels of a 32-channel k-step), the head convs (policy 32 + value 3
-// channels = three 16-column fragments, waves 0..2) read the final tile and write the FC inputs.
-struct Net16Params {
-    const BgState* states;       // [G]
-    const u32x4* winit;          // [16 nfrags][9][64] x 16 B   (k-step = tap; channels 0..5 real of 32)
-    const float* binit;          // [256]
-    const u32x4* wt;             // [38][16][72][64] x 16 B
-    const float* bt;             // [38][256]
-    const u32x4* whead;          // [4 nfrags][72][64] x 16 B   (channels 0..31 policy, 32..34 value)
-    const float* bhead;          // [64]
-    uint16_t* hp;                // [G][768] bf16, k' = p*32 + c
-    float* hv;                   // [G][72]  f32,  k' = p*3 + c
-    int G;
-};
-
-template <int GT, int NW, int PF>
-__global__ __launch_bounds__(64 * NW) void k_net16(Net16Params P) {
-    constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, RS = 528, NT = 64 * NW, NFR = 16 / NW;
-    constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tx = smem;
-    char* th = smem + TILE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS, M = P.G * 24;
-
-    const u32x4* wp0 = P.wt + (size_t)(wave * NFR) * 72 * 64 + lane;
-    u32x4 bq[PF][NFR];
-#pragma unroll
-    for (int i = 0; i < PF; ++i)
-#pragma unroll
-        for (int q = 0; q < NFR; ++q) bq[i][q] = wp0[((size_t)q * 72 + i) * 64];
-
-    // input planes (backgammon_logic.rs:198-252) -> th, 64 bytes (32 channels, 6 real) per row
-    for (int i = tid; i < ROWS * 4; i += NT) {
-        const int r = i >> 2, ch = i & 3;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ch == 0 && row0 + r < M) {
-            const BgState st = P.states[(row0 + r) / 24];
-            const int p = (row0 + r) % 24;
-            uint32_t w[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                w[c] = (uint32_t)f2bf(bg_plane_dev(st, 2 * c, p)) | ((uint32_t)f2bf(bg_plane_dev(st, 2 * c + 1, p)) << 16);
-            v = u32x4{w[0], w[1], w[2], 0u};
-        }
-        *(u32x4*)(th + r * RS + ch * 16) = v;
-    }
-    for (int i = tid; i < 2 * 36; i += NT) {
-        char* tl = i < 36 ? tx : th;
-        *(u32x4*)(tl + ROWS * RS + (i % 36) * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
-    uint32_t basep[9][(MF + 1) / 2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int h = 0; h < (MF + 1) / 2; ++h) basep[t][h] = 0;
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-        const int R = 16 * f + (lane & 15);
-        const int p = R % 24, y = p / 6, x = p % 6;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool ok = R < ROWS && (unsigned)(y + dy) < 4u && (unsigned)(x + dx) < 6u;
-            const uint32_t ad = (uint32_t)((ok ? R + 6 * dy + dx : ROWS) * RS + (lane >> 4) * 16);
-            basep[t][f >> 1] |= (f & 1) ? ad << 16 : ad;
-        }
-    }
-    auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
-    __syncthreads();
-
-    // ---- init block: conv 6 -> 256 + BN + ReLU (nnet.rs:64-67), th -> tx, one 32-channel k-step per tap ----
-    {
-        f32x4 acc[MF][NFR];
-#pragma unroll
-        for (int f = 0; f < MF; ++f)
-#pragma unroll
-            for (int q = 0; q < NFR; ++q) acc[f][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            bf16x8 b[NFR];
-#pragma unroll
-            for (int q = 0; q < NFR; ++q) b[q] = __builtin_bit_cast(bf16x8, P.winit[((size_t)(wave * NFR + q) * 9 + t) * 64 + lane]);
-#pragma unroll
-            for (int f = 0; f < MF; ++f) {
-                const bf16x8 a = *(const bf16x8*)(th + baddr(t, f));
-#pragma unroll
-                for (int q = 0; q < NFR; ++q) acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a, acc[f][q], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NFR; ++q) {
-            const int n0 = (wave * NFR + q) * 16 + (lane >> 4) * 4;
-            const float4 bv = *(const float4*)(P.binit + n0);
-#pragma unroll
-            for (int f = 0; f < MF; ++f) {
-                const int r = 16 * f + (lane & 15);
-                if (ROWS % 16 != 0 && r >= ROWS) continue;
-                float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
-                v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
-                uint2 o;
-                o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                *(uint2*)(tx + r * RS + n0 * 2) = o;
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- tower (nnet.rs:69-73) ----
-    for (int blk = 0; blk < 19; ++blk) {
-        const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTower16LayerStride;
-        const u32x4* w2 = w1 + kTower16LayerStride;
-        const u32x4* w3 = blk < 18 ? w2 + kTower16LayerStride : w2;
-        tower_layer16<false, GT, NW, PF>(tx, th, w1, w2, P.bt + (2 * blk) * 256, basep, bq, lane, wave);
-        tower_layer16<true, GT, NW, PF>(th, tx, w2, w3, P.bt + (2 * blk + 1) * 256, basep, bq, lane, wave);
-    }
-
-    // ---- head convs (nnet.rs:76-78, 88-90): 3 useful 16-channel fragments, one per wave ----
-    if (wave < 3) {
-        const u32x4* wh = P.whead + (size_t)wave * 72 * 64 + lane;
-        f32x4 acc[MF];
-#pragma unroll
-        for (int f = 0; f < MF; ++f) acc[f] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        u32x4 bn = wh[0];
-        for (int cs = 0; cs < 8; ++cs) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, bn);
-                const int nx = cs * 9 + t + 1;
-                bn = wh[(size_t)(nx < 72 ? nx : 71) * 64];
-#pragma unroll
-                for (int f = 0; f < MF; ++f) {
-                    const bf16x8 a = *(const bf16x8*)(tx + baddr(t, f) + cs * 64);
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[f], 0, 0, 0);
-                }
-            }
-        }
-        const int n0 = wave * 16 + (lane >> 4) * 4;
-        const float4 bv = *(const float4*)(P.bhead + n0);
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int r = 16 * f + (lane & 15), gr = row0 + r;
-            if ((ROWS % 16 != 0 && r >= ROWS) || gr >= M) continue;
-            float v0 = acc[f][0] + bv.x, v1 = acc[f][1] + bv.y, v2 = acc[f][2] + bv.z, v3 = acc[f][3] + bv.w;
-            v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
-            const int g = gr / 24, p = gr % 24;
-            if (n0 < 32) {
-                uint2 o;
-                o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-                *(uint2*)(P.hp + (size_t)g * 768 + p * 32 + n0) = o;
-            } else if (n0 == 32) {
-                float* ov = P.hv + (size_t)g * 72 + p * 3;
-                ov[0] = v0; ov[1] = v1; ov[2] = v2;
-            }
-        }
-    }
-}
-
 // policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight
 // from L2 (the layer is ~0.2 % of the network's FLOPs).
 __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
@@ -1555,28 +1393,6 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
     tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,
                             binit, whead16, bhead, hp, hv, RowMap{row_slot, n_rows, 3, main_cap});
 }
-template <int GT, int NW, int PF>
-static void net16_launch(hipStream_t st, const Net16Params& P) {
-    static bool attr_set = false;
-    constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
-    constexpr int lds = 2 * tile;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_net16<GT, NW, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_net16<GT, NW, PF>), dim3((P.G + GT - 1) / GT), dim3(64 * NW), lds, st, P);
-}
-// init block + tower + head convs in one launch; geometry 3 / 4 / 5 = 2 / 3 / 4 boards per workgroup
-void launch_net16(hipStream_t st, int geometry, const void* states, const void* winit, const float* binit, const void* wt,
-                  const float* bt, const void* whead, const float* bhead, uint16_t* hp, float* hv, int G) {
-    const Net16Params P{(const BgState*)states, (const u32x4*)winit, binit, (const u32x4*)wt, bt, (const u32x4*)whead, bhead, hp, hv, G};
-    switch (geometry) {
-        case 3: net16_launch<2, 8, 9>(st, P); break;
-        case 4: net16_launch<3, 4, 6>(st, P); break;
-        default: net16_launch<4, 4, 3>(st, P); break;
-    }
-}
-
 // geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9: 16x16x32 MFMA (wt16 = 16-column fragments):
 // 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 3, 7, 8)
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,

@@ -143,7 +143,6 @@ def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(33, 4)[:301]          # ragged: not a multiple of 2, 3 or 4 boards
     monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
-    monkeypatch.setenv("DIEE_NET16", "1" if geom == 4 else "0")   # geometry 4 also covers the whole-network launch (k_net16)
     e = diee_amd.Engine(0); e.load_weights(blob)
     p, v = e.forward_t(states)
     monkeypatch.setenv("DIEE_TOWER_TABLE", "0:0")
