@@ -17,6 +17,7 @@ namespace diee {
 namespace {
 
 constexpr int F = 256, BLOCKS = 19, A = 1352, CIN = 6, PH = 32, VH = 3;
+constexpr int kFullRestBoards = 928;      // above it a remainder rides with the 4-board full-pass launch (kFullRest in nn_kernels.hip)
 
 struct ConvOff { size_t w, b; int cout, cin; };
 struct BnOff { size_t g, b, m, v; int c; };
@@ -390,7 +391,10 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     nn_reserve(e, G);
     hipStream_t st = e.stream;
     const int tg = W.tower_geometry_for(G);
-    if (rows && W.compact && !policy_dev && G > W.compact_above && tg >= 2 && W.cluster_init && W.fused_heads) {
+    // (one full pass of the chip, 929 ... 1024 live games, is the opening and middle game: hardly a terminal leaf, and the row
+    // map + the two remainder launches that stay empty cost 14 us per evaluation: those batches run plain)
+    const bool one_full_pass = G > kFullRestBoards && G <= W.full_chip_boards;
+    if (rows && W.compact && !policy_dev && G > W.compact_above && !one_full_pass && tg >= 2 && W.cluster_init && W.fused_heads) {
         const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
         const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
         W.rows_log.ensure(kRowsLog);
