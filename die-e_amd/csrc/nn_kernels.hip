@@ -24,6 +24,9 @@
 #ifndef DIEE_TOWER_BORDER
 #define DIEE_TOWER_BORDER 1      // 1 = the 4-board fused tower skips (tap, fragment) pairs that are all zero padding
 #endif
+#ifndef DIEE_TOWER_PRIO
+#define DIEE_TOWER_PRIO 1         // 1 = waves 4..7 of the 8-wave fused tower run at s_setprio 1
+#endif
 #ifndef DIEE_CL_PD
 #define DIEE_CL_PD 0              // cluster tower: LDS prefetch distance in k-steps (0 = by geometry)
 #endif
@@ -943,7 +946,9 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             *(uint2*)(tout + off) = o;
         }
     }
+#if DIEE_TOWER_ABLATE != 5      // 5: timing experiment, what the one barrier per layer costs (wrong results)
     __syncthreads();
+#endif
 }
 
 // Which boards a launch of the fused tower evaluates when the batch is COMPACTED on the device (the search skips the
@@ -1102,6 +1107,11 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
     unsigned long long t0 = 0, r0 = 0;
     if (DIEE_TOWER_ABLATE == 3) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
+#if DIEE_TOWER_PRIO
+    // the second-dispatched half of an 8-wave workgroup loses every issue arbitration against its older SIMD partner
+    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one static priority for that half, no per-segment flips
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int blk = 0; blk < 19; ++blk) {
         const u32x4* w1 = wp0 + (size_t)(2 * blk) * kTower16LayerStride;
         const u32x4* w2 = w1 + kTower16LayerStride;
