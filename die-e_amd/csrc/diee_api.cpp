@@ -207,9 +207,14 @@ diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint3
 
 // ---- training-step kernels: stateless, on the caller's stream ----
 static const float* zero_bias256() {
-    static float* z = nullptr;                                   // one 1 KB allocation per process and device use is enough here
-    if (!z) { if (hipMalloc((void**)&z, 256 * sizeof(float)) != hipSuccess) return nullptr; (void)hipMemset(z, 0, 256 * sizeof(float)); }
-    return z;
+    static float* z[16] = {nullptr};                             // one 1 KB allocation per device the process trains on
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!z[dev]) {
+        if (hipMalloc((void**)&z[dev], 256 * sizeof(float)) != hipSuccess) { z[dev] = nullptr; return nullptr; }
+        (void)hipMemset(z[dev], 0, 256 * sizeof(float));
+    }
+    return z[dev];
 }
 diee_status diee_train_pack_conv3x3(const float* w, void* wpack, int transpose, void* stream) {
     if (!w || !wpack) return DIEE_ERR_ARG;

@@ -24,6 +24,9 @@
 #ifndef DIEE_TOWER_BORDER
 #define DIEE_TOWER_BORDER 1      // 1 = the 4-board fused tower skips (tap, fragment) pairs that are all zero padding
 #endif
+#ifndef DIEE_TOWER_STAGGER
+#define DIEE_TOWER_STAGGER 0      // s_sleep argument (x 64 cycles) for waves 4..7 at the start of every fused-tower layer (0: none)
+#endif
 #ifndef DIEE_TOWER_PRIO
 #define DIEE_TOWER_PRIO 1         // 1 = waves 4..7 of the 8-wave fused tower run at s_setprio 1
 #endif
@@ -870,6 +873,11 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #pragma unroll
         for (int q = 0; q < NFR; ++q) acc[f][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     bf16x8 a[2][MF];
+#if DIEE_TOWER_STAGGER
+    // the two waves of a SIMD run the same program and leave the layer barrier together: a short delay for the upper
+    // half puts one wave's load phase beside its partner's MFMA phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 9)
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_sleep(DIEE_TOWER_STAGGER);
+#endif
     // per-lane LDS addresses of the A fragments are < 64 KiB: two per register (keeps the 4-board geometry out of scratch)
     auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
 #pragma unroll

@@ -197,7 +197,12 @@ bool cluster_starved(Engine& e) {
     SearchBufs& B = *e.search;
     e.d2h(B.live_host + 1 + kMaxSegments, e.flags_dev.p, 1);
     e.sync();
-    if (!(B.live_host[1 + kMaxSegments] & 4u)) return false;
+    // tests: DIEE_TEST_STARVE_AT=k treats the k-th check of the process as a starved hand-over (the fallback path has
+    // no other way to be exercised on a box with one process per GPU)
+    static const int starve_at = getenv("DIEE_TEST_STARVE_AT") ? atoi(getenv("DIEE_TEST_STARVE_AT")) : -1;
+    static int checks = 0;
+    const bool forced = ++checks == starve_at;
+    if (!(B.live_host[1 + kMaxSegments] & 4u) && !forced) return false;
     nn_disable_cluster(e);                                            // clears the flag bit and re-arms the counters
     fprintf(stderr, "[diee] cluster tower: a workgroup hand-over starved (is another process using this GPU?); "
                     "falling back to the per-layer kernels for the rest of this process\n");

@@ -69,3 +69,30 @@ def test_8192_games_on_one_gpu(oracle):
     assert st["move_steps"] == 2 and st["plies"] == 2 * 8192 and st["nn_evals"] == 2 * 4 * 8192
     assert st["illegal_decodes"] == 0
     e.close()
+
+
+def test_starved_cluster_launch_falls_back_and_repeats_the_search(oracle):
+    """a starved in-launch hand-over of the cluster tower (another process on the GPU) must not fail the call: the
+    engine drops the cluster tower for the rest of the process and repeats that move-step's search on the per-layer
+    kernels, which compute the same bits.  Forced here through DIEE_TEST_STARVE_AT in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import diee_amd
+e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+cfg = diee_amd.MctsConfig(iterations=6, c=2.0, round_limit=30, dir_alpha=0.3, dir_eps=0.25)
+out = e.self_play_parallel(9, cfg, 1.25, 77, ref_quirks=True)
+print("RESULT", hashlib.sha256(out["ps"].tobytes() + out["state"].tobytes() + out["outcome"].tobytes()).hexdigest(),
+      out["stats"]["nn_evals"], out["stats"]["expansions"], out["stats"]["move_steps"])
+""" % root
+    res = {}
+    for name, env in (("normal", {}), ("starved", {"DIEE_TEST_STARVE_AT": "3"})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        res[name] = ([l for l in p.stdout.decode().splitlines() if l.startswith("RESULT")][0], p.stderr.decode())
+    assert "falling back to the per-layer kernels" in res["starved"][1] and "falling back" not in res["normal"][1]
+    assert res["starved"][0] == res["normal"][0]          # same records, same counters: the repeated search left no trace
