@@ -113,3 +113,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "diee_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def _build_cpp_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "self_play")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "self_play.cpp"), "-L", os.path.join(ROOT, "die-e_amd"), "-ldiee",
+                           "-Wl,-rpath," + os.path.join(ROOT, "die-e_amd"), "-o", exe])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/diee.hpp (the compiled-language mirror of the reference's interface for the path) + examples/self_play.cpp
+    against libdiee.so: what a Rust host's extern "C" binding would do, from C++"""
+    import subprocess
+    import torch
+    exe = _build_cpp_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run is tests/test_host_gpu.py's")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"no HIP device" in p.stderr

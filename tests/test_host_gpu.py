@@ -103,3 +103,19 @@ def test_cli_end_to_end_in_a_child_process(tmp_path):
     assert len(list(games.iterdir())) == 400                                      # versus.rs:160: 400 games
     rc, out = run("replay", "-g", str(next(games.iterdir())))
     assert rc == 0 and "Player 1: Random" in out
+
+
+def test_cpp_host_drives_the_engine_through_the_c_abi(tmp_path):
+    """examples/self_play.cpp (g++, include/diee.hpp over include/diee.h): legal plays, one search, a self-play batch and
+    two batches side by side from a compiled host; batch 0 of the pipelined call equals the single call"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "self_play")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "self_play.cpp"),
+                           "-L", os.path.join(root, "die-e_amd"), "-ldiee", "-Wl,-rpath," + os.path.join(root, "die-e_amd"), "-o", exe])
+    p = subprocess.run([exe, "6", "6", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert "15 legal plays, first code 785" in out                     # SURVEY 8(c): the 15 opening plays, code of the first
+    assert "self_play_parallel: 6 games" in out and "equals the single call: yes" in out
