@@ -30,6 +30,9 @@
 #ifndef DIEE_TOWER_PRIO
 #define DIEE_TOWER_PRIO 1         // 1 = waves 4..7 of the 8-wave fused tower run at s_setprio 1
 #endif
+#ifndef DIEE_CL_POLL_SLEEP
+#define DIEE_CL_POLL_SLEEP 2      // s_sleep argument (x 64 cycles) between two polls of the cluster tower's input tile (6: same, 12 / 24: slower)
+#endif
 #ifndef DIEE_CL_PD
 #define DIEE_CL_PD 0              // cluster tower: LDS prefetch distance in k-steps (0 = by geometry)
 #endif
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                     for (int k = 0; k < BATCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
                     if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
                     if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(DIEE_CL_POLL_SLEEP);
                 }
                 if (k0 == 0) CL_STAMP(0)            // first batch of the tile polled in
 #pragma unroll
