@@ -251,6 +251,12 @@ diee_status diee_train_bn_relu_bwd(const void* dy, const void* y, const void* x,
                        scratch, dgamma, dbeta, (uint16_t*)dx, (uint16_t*)dres, rows);
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
+size_t diee_train_wgrad_scratch_floats(void) { return wgrad_scratch_floats(); }
+diee_status diee_train_wgrad3x3(const void* x, const void* dy, float* dw, int boards, float* scratch, void* stream) {
+    if (!x || !dy || !dw || !scratch || boards <= 0) return DIEE_ERR_ARG;
+    launch_wgrad3x3((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy, scratch, dw, boards);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
 diee_status diee_train_colsum(const void* a, float* out, int rows, float* scratch, void* stream) {
     if (!a || !out || !scratch || rows <= 0) return DIEE_ERR_ARG;
     launch_colsum((hipStream_t)stream, (const uint16_t*)a, scratch, out, rows);

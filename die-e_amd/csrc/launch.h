@@ -43,6 +43,8 @@ void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, 
 void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
                         const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
                         uint16_t* dres, int M);
+size_t wgrad_scratch_floats();
+void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards);
 void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);
 void launch_pack_conv_w(hipStream_t st, const float* w_oihw, uint16_t* wpack, int transpose);
 void launch_im2col3x3(hipStream_t st, const uint16_t* x, uint16_t* col, int boards);

@@ -20,7 +20,10 @@ import torch
 
 from . import load_library
 
+import os
+
 _N_PACK = 8 * 144 * 64 * 8          # bf16 elements of one packed 256x256x3x3 convolution
+WGRAD_GEMM = os.environ.get("DIEE_WGRAD", "") == "gemm"
 
 
 def _ptr(t):
@@ -68,10 +71,15 @@ class Conv3x3Tok(torch.autograd.Function):
             dx = torch.empty_like(x)
             _chk(L.diee_train_conv3x3(_ptr(dy), _ptr(wp), None, _ptr(dx), boards, _stream()), "conv3x3 dgrad")
         if ctx.needs_input_grad[1]:
-            col = torch.empty(x.shape[0], 2304, dtype=torch.bfloat16, device=x.device)
-            _chk(L.diee_train_im2col3x3(_ptr(x), _ptr(col), boards, _stream()), "im2col")
-            dwf = torch.matmul(col.t(), dy)                      # [2304 = t*256 + c, 256 = n], fp32 accumulation inside
-            dw = dwf.float().view(3, 3, 256, 256).permute(3, 2, 0, 1).contiguous()      # -> [n][c][ky][kx]
+            if WGRAD_GEMM:                                       # DIEE_WGRAD=gemm: im2col + the framework's GEMM (the round-2 first version)
+                col = torch.empty(x.shape[0], 2304, dtype=torch.bfloat16, device=x.device)
+                _chk(L.diee_train_im2col3x3(_ptr(x), _ptr(col), boards, _stream()), "im2col")
+                dwf = torch.matmul(col.t(), dy)                  # [2304 = t*256 + c, 256 = n], fp32 accumulation inside
+                dw = dwf.float().view(3, 3, 256, 256).permute(3, 2, 0, 1).contiguous()      # -> [n][c][ky][kx]
+            else:                                                # hand-written: transposed LDS reads + MFMA, fp32 out
+                dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
+                scratch = torch.empty(int(L.diee_train_wgrad_scratch_floats()), dtype=torch.float32, device=x.device)
+                _chk(L.diee_train_wgrad3x3(_ptr(x), _ptr(dy), _ptr(dw), boards, _ptr(scratch), _stream()), "wgrad")
         if ctx.needs_input_grad[2]:
             db = torch.empty(256, dtype=torch.float32, device=x.device)
             scratch = torch.empty(int(L.diee_train_scratch_floats(x.shape[0])), dtype=torch.float32, device=x.device)

@@ -204,6 +204,11 @@ diee_status diee_train_bn_relu_fwd(const void* x_bf16, const void* res_bf16 /*or
 diee_status diee_train_bn_relu_bwd(const void* dy_bf16, const void* y_bf16, const void* x_bf16, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                                    void* dx_bf16, void* dres_bf16, int rows, float* scratch, void* stream);
+/* weight gradient of the tower convolution, hand-written: dW[n][c][ky][kx] (fp32, OIHW) = sum over rows of
+ * x[row + shift(ky,kx)][c] * dy[row][n]; scratch: diee_train_wgrad_scratch_floats() floats.  Deterministic. */
+size_t      diee_train_wgrad_scratch_floats(void);
+diee_status diee_train_wgrad3x3(const void* x_bf16, const void* dy_bf16, float* dw_oihw /*[256][256][3][3]*/, int boards,
+                                float* scratch, void* stream);
 /* out[c] = sum over rows of a[row][c] (the convolution's bias gradient) */
 diee_status diee_train_colsum(const void* a_bf16, float* out /*[256]*/, int rows, float* scratch, void* stream);
 
