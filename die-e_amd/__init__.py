@@ -41,7 +41,8 @@ assert BG_STATE.itemsize == 32
 EXPORTS = [
     "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
     "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
-    "diee_self_play_multi", "diee_set_invariant_nn", "diee_train_pack_conv3x3", "diee_train_conv3x3", "diee_train_im2col3x3",
+    "diee_self_play_multi", "diee_set_invariant_nn", "diee_train_pack_conv3x3", "diee_train_pack_conv3x3_multi",
+    "diee_train_conv3x3", "diee_train_im2col3x3",
     "diee_train_scratch_floats", "diee_train_bn_relu_fwd", "diee_train_bn_relu_bwd", "diee_train_colsum",
     "diee_train_wgrad_scratch_floats", "diee_train_wgrad3x3",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
@@ -126,6 +127,7 @@ def load_library(path=None):
     L.diee_self_play_multi.argtypes = [vp, vp, u32, vp, f32, u32, u32, vp, vp]; L.diee_self_play_multi.restype = C.c_int
     L.diee_set_invariant_nn.argtypes = [vp, C.c_int]; L.diee_set_invariant_nn.restype = C.c_int
     L.diee_train_pack_conv3x3.argtypes = [vp, vp, C.c_int, vp]; L.diee_train_pack_conv3x3.restype = C.c_int
+    L.diee_train_pack_conv3x3_multi.argtypes = [C.POINTER(vp), C.c_int, vp, vp]; L.diee_train_pack_conv3x3_multi.restype = C.c_int
     L.diee_train_conv3x3.argtypes = [vp, vp, vp, vp, C.c_int, vp]; L.diee_train_conv3x3.restype = C.c_int
     L.diee_train_im2col3x3.argtypes = [vp, vp, C.c_int, vp]; L.diee_train_im2col3x3.restype = C.c_int
     L.diee_train_scratch_floats.argtypes = [C.c_int]; L.diee_train_scratch_floats.restype = C.c_size_t

@@ -221,6 +221,13 @@ diee_status diee_train_pack_conv3x3(const float* w, void* wpack, int transpose, 
     launch_pack_conv_w((hipStream_t)stream, w, (uint16_t*)wpack, transpose);
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
+diee_status diee_train_pack_conv3x3_multi(const float* const* w, int n, void* wpack, void* stream) {
+    if (!w || !wpack || n <= 0 || n > kMaxPackLayers) return DIEE_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!w[i]) return DIEE_ERR_ARG;
+    launch_pack_conv_w_multi((hipStream_t)stream, w, n, (uint16_t*)wpack);
+    return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
+}
 diee_status diee_train_conv3x3(const void* x, const void* wpack, const float* bias, void* y, int boards, void* stream) {
     if (!x || !wpack || !y || boards <= 0) return DIEE_ERR_ARG;
     if (!bias) bias = zero_bias256();

@@ -47,6 +47,9 @@ size_t wgrad_scratch_floats();
 void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards);
 void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);
 void launch_pack_conv_w(hipStream_t st, const float* w_oihw, uint16_t* wpack, int transpose);
+constexpr int kMaxPackLayers = 64;
+// w: host array of n (<= kMaxPackLayers) device pointers; wpack [n][2 = forward, transposed][589 824] bf16
+void launch_pack_conv_w_multi(hipStream_t st, const float* const* w, int n, uint16_t* wpack);
 void launch_im2col3x3(hipStream_t st, const uint16_t* x, uint16_t* col, int boards);
 void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, const float* bias, float* logits, int G,
                       const uint32_t* n_rows = nullptr);   // n_rows non-null: device-side row count of a compacted batch (<= G)

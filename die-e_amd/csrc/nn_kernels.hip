@@ -1501,6 +1501,34 @@ __global__ void k_pack_conv_w(const float* __restrict__ w, uint16_t* __restrict_
     const float v = transpose ? w[((size_t)c * 256 + n) * 9 + (8 - t)] : w[((size_t)n * 256 + c) * 9 + t];
     out[i] = f2bf(v);
 }
+// the same packing for every tower convolution of the net in one launch, both layouts (forward, transposed), with the
+// gathers staged through LDS: block (s*16 + cs, layout, layer) reads 32 x 16 x 9 weights in contiguous runs and writes
+// the 9 fragments [cs*9 .. cs*9 + 8] of output tile s as one 9216-byte run
+struct PackPtrs { const float* w[kMaxPackLayers]; };
+__global__ __launch_bounds__(256) void k_pack_conv_w_multi(PackPtrs ptrs, uint16_t* __restrict__ out) {
+    __shared__ float tile[32 * 145];
+    const int tid = threadIdx.x, s = blockIdx.x >> 4, cs = blockIdx.x & 15, transpose = blockIdx.y;
+    const float* __restrict__ w = ptrs.w[blockIdx.z];
+    for (int i = tid; i < 32 * 144; i += 256) {
+        if (!transpose) {
+            const int nl = i / 144, r = i - nl * 144;                // run of 16 c x 9 taps of output channel s*32 + nl
+            tile[nl * 145 + r] = w[((size_t)(s * 32 + nl) * 256 + cs * 16) * 9 + r];
+        } else {
+            const int cl = i / 288, r = i - cl * 288, nl = r / 9, t = 8 - (r - nl * 9);
+            tile[nl * 145 + cl * 9 + t] = w[((size_t)(cs * 16 + cl) * 256 + s * 32) * 9 + r];
+        }
+    }
+    __syncthreads();
+    uint16_t* o = out + ((size_t)blockIdx.z * 2 + transpose) * (8 * 144 * 64 * 8) + (size_t)(s * 144 + cs * 9) * 512;
+    for (int i = tid; i < 9 * 64; i += 256) {
+        const int t = i >> 6, lane = i & 63;
+        const float* src = tile + (lane & 31) * 145 + 8 * (lane >> 5) * 9 + t;
+        u32x4 v;
+        v.x = f2bf(src[0]) | ((uint32_t)f2bf(src[9]) << 16);   v.y = f2bf(src[18]) | ((uint32_t)f2bf(src[27]) << 16);
+        v.z = f2bf(src[36]) | ((uint32_t)f2bf(src[45]) << 16); v.w = f2bf(src[54]) | ((uint32_t)f2bf(src[63]) << 16);
+        *(u32x4*)(o + (size_t)i * 8) = v;
+    }
+}
 // col[row][t*256 + c] = x[row + 6*dy + dx][c] inside the board, 0 outside (16 bytes per thread)
 __global__ void k_im2col3x3(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int M) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1513,6 +1541,11 @@ __global__ void k_im2col3x3(const uint16_t* __restrict__ x, uint16_t* __restrict
 }
 void launch_pack_conv_w(hipStream_t st, const float* w, uint16_t* out, int transpose) {
     hipLaunchKernelGGL(k_pack_conv_w, dim3(8 * 144 * 64 * 8 / 256), dim3(256), 0, st, w, out, transpose);
+}
+void launch_pack_conv_w_multi(hipStream_t st, const float* const* w, int n, uint16_t* out) {
+    PackPtrs p{};
+    for (int i = 0; i < n; ++i) p.w[i] = w[i];
+    hipLaunchKernelGGL(k_pack_conv_w_multi, dim3(128, 2, n), dim3(256), 0, st, p, out);
 }
 void launch_im2col3x3(hipStream_t st, const uint16_t* x, uint16_t* col, int boards) {
     const size_t n = (size_t)boards * 24 * 9 * 32;

@@ -43,33 +43,35 @@ class Conv3x3Tok(torch.autograd.Function):
     """y[M,256] = conv3x3 over 4x6 boards of x[M,256] (M = boards*24, bf16) with w[256,256,3,3] (fp32) + b[256] (fp32)"""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, packed=None):
+        """packed: [2, 589824] bf16 (forward, transposed) from pack_tower_weights, or None = pack here"""
         L = load_library()
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == 256 and x.shape[0] % 24 == 0
         assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (256, 256, 3, 3)
         boards = x.shape[0] // 24
-        wp = torch.empty(_N_PACK, dtype=torch.bfloat16, device=x.device)
-        _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(wp), 0, _stream()), "pack")
+        if packed is None:
+            packed = torch.empty(2, _N_PACK, dtype=torch.bfloat16, device=x.device)
+            _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(packed[0]), 0, _stream()), "pack")
+            _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(packed[1]), 1, _stream()), "pack (transposed)")
+        assert packed.dtype == torch.bfloat16 and packed.is_contiguous() and tuple(packed.shape) == (2, _N_PACK)
         y = torch.empty_like(x)
         bias = b.detach().float().contiguous()
-        _chk(L.diee_train_conv3x3(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), boards, _stream()), "conv3x3 forward")
-        ctx.save_for_backward(x, w)
+        _chk(L.diee_train_conv3x3(_ptr(x), _ptr(packed[0]), _ptr(bias), _ptr(y), boards, _stream()), "conv3x3 forward")
+        ctx.save_for_backward(x, packed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = load_library()
-        x, w = ctx.saved_tensors
+        x, packed = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         boards = x.shape[0] // 24
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wp = torch.empty(_N_PACK, dtype=torch.bfloat16, device=x.device)
-            _chk(L.diee_train_pack_conv3x3(_ptr(w), _ptr(wp), 1, _stream()), "pack (transposed)")
             dx = torch.empty_like(x)
-            _chk(L.diee_train_conv3x3(_ptr(dy), _ptr(wp), None, _ptr(dx), boards, _stream()), "conv3x3 dgrad")
+            _chk(L.diee_train_conv3x3(_ptr(dy), _ptr(packed[1]), None, _ptr(dx), boards, _stream()), "conv3x3 dgrad")
         if ctx.needs_input_grad[1]:
             if WGRAD_GEMM:                                       # DIEE_WGRAD=gemm: im2col + the framework's GEMM (the round-2 first version)
                 col = torch.empty(x.shape[0], 2304, dtype=torch.bfloat16, device=x.device)
@@ -84,7 +86,7 @@ class Conv3x3Tok(torch.autograd.Function):
             db = torch.empty(256, dtype=torch.float32, device=x.device)
             scratch = torch.empty(int(L.diee_train_scratch_floats(x.shape[0])), dtype=torch.float32, device=x.device)
             _chk(L.diee_train_colsum(_ptr(dy), _ptr(db), x.shape[0], _ptr(scratch), _stream()), "colsum")
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class BnReluTok(torch.autograd.Function):
@@ -131,8 +133,21 @@ def bn_relu_tok(bn, x, res=None):
                            bn.running_var if bn.training else None, bn.momentum, bn.eps)
 
 
-def conv3x3_tok(x, conv):
-    return Conv3x3Tok.apply(x, conv.weight, conv.bias)
+def conv3x3_tok(x, conv, packed=None):
+    return Conv3x3Tok.apply(x, conv.weight, conv.bias, packed)
+
+
+def pack_tower_weights(convs):
+    """the forward and the transposed fragment packing of every 256x256x3x3 convolution in `convs`, one launch:
+    [len(convs), 2, 589824] bf16"""
+    L = load_library()
+    ws = [c.weight for c in convs]
+    for w in ws:
+        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (256, 256, 3, 3)
+    out = torch.empty(len(ws), 2, _N_PACK, dtype=torch.bfloat16, device=ws[0].device)
+    ptrs = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    _chk(L.diee_train_pack_conv3x3_multi(ptrs, len(ws), _ptr(out), _stream()), "pack (all layers)")
+    return out
 
 
 def to_tokens(h):
@@ -155,9 +170,10 @@ def forward_train_tokens(net, x):
     B = x.shape[0]
     h = torch.relu(net.init_bn(net.init_conv(x)))
     t = to_tokens(h)
-    for blk in net.blocks:                                       # ResBlock::forward_t, nnet.rs:24-34
-        g = bn_relu_tok(blk.bn1, conv3x3_tok(t, blk.conv1))
-        t = bn_relu_tok(blk.bn2, conv3x3_tok(g, blk.conv2), res=t)
+    packed = pack_tower_weights([c for blk in net.blocks for c in (blk.conv1, blk.conv2)])
+    for i, blk in enumerate(net.blocks):                         # ResBlock::forward_t, nnet.rs:24-34
+        g = bn_relu_tok(blk.bn1, conv3x3_tok(t, blk.conv1, packed[2 * i]))
+        t = bn_relu_tok(blk.bn2, conv3x3_tok(g, blk.conv2, packed[2 * i + 1]), res=t)
     h = from_tokens(t, B)
     logits = net.p_fc(torch.relu(net.p_bn(net.p_conv(h))).flatten(1))
     value = torch.tanh(net.v_fc(torch.relu(net.v_bn(net.v_conv(h))).flatten(1)))

@@ -189,6 +189,9 @@ diee_status diee_self_play_multi(diee_ctx*, const diee_batch* batches, uint32_t 
  *   dgrad     dx = conv3x3(dy, W'), W' = W transposed and flipped   diee_train_conv3x3(dy, pack(W, 1), NULL, dx)
  *   wgrad     dW[t*256 + c][n] = col^T x dy, col = diee_train_im2col3x3(x)   (the GEMM is the framework's)  */
 diee_status diee_train_pack_conv3x3(const float* w_oihw /*[256][256][3][3]*/, void* wpack /*589 824 bf16*/, int transpose, void* stream);
+/* every tower convolution of a step in one launch: w = host array of n (<= 64) device pointers to OIHW fp32 weights;
+ * wpack[n][2][589 824] bf16 receives the forward (0) and the transposed (1) packing of each */
+diee_status diee_train_pack_conv3x3_multi(const float* const* w_oihw, int n, void* wpack, void* stream);
 diee_status diee_train_conv3x3(const void* x_bf16, const void* wpack, const float* bias /*[256] or NULL*/, void* y_bf16,
                                int boards, void* stream);
 diee_status diee_train_im2col3x3(const void* x_bf16, void* col_bf16 /*[boards*24][2304]*/, int boards, void* stream);

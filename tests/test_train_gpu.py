@@ -39,6 +39,27 @@ def test_conv3x3_tok_forward_and_gradients_match_fp32_autograd():
         assert ex < 1e-2 and ew < 1e-2 and eb < 1e-2
 
 
+def test_all_layer_weight_packing_equals_the_per_layer_packing():
+    """pack_tower_weights (one launch, LDS-staged) == diee_train_pack_conv3x3 per layer and layout, bit for bit"""
+    import torch
+    import ctypes as C
+    import diee_amd
+    ops = importlib.import_module("die-e_amd.train_ops")
+    L = diee_amd.load_library()
+    torch.manual_seed(3)
+    convs = [torch.nn.Conv2d(256, 256, 3, padding=1).cuda() for _ in range(5)]
+    multi = ops.pack_tower_weights(convs)
+    assert tuple(multi.shape) == (5, 2, 589824)
+    for i, c in enumerate(convs):
+        for tr in (0, 1):
+            one = torch.empty(589824, dtype=torch.bfloat16, device="cuda")
+            assert L.diee_train_pack_conv3x3(C.c_void_p(c.weight.data_ptr()), C.c_void_p(one.data_ptr()), tr, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(multi[i, tr].view(torch.int16), one.view(torch.int16)), (i, tr)
+    ptrs = (C.c_void_p * 65)(*[convs[0].weight.data_ptr()] * 65)
+    assert L.diee_train_pack_conv3x3_multi(ptrs, 65, C.c_void_p(multi.data_ptr()), None) != 0      # more than 64 layers: refused
+
+
 def test_fused_bn_relu_matches_pytorch_batch_norm():
     """BatchNorm (train mode) + residual + ReLU in one pass, forward and backward, against torch's own ops on the same
     bf16-rounded inputs; running statistics updated like nn.BatchNorm2d"""
