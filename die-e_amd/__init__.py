@@ -132,7 +132,7 @@ def load_library(path=None):
     L.diee_train_im2col3x3.argtypes = [vp, vp, C.c_int, vp]; L.diee_train_im2col3x3.restype = C.c_int
     L.diee_train_scratch_floats.argtypes = [C.c_int]; L.diee_train_scratch_floats.restype = C.c_size_t
     L.diee_train_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, C.c_int, vp, vp]; L.diee_train_bn_relu_fwd.restype = C.c_int
-    L.diee_train_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]; L.diee_train_bn_relu_bwd.restype = C.c_int
+    L.diee_train_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]; L.diee_train_bn_relu_bwd.restype = C.c_int
     L.diee_train_colsum.argtypes = [vp, vp, C.c_int, vp, vp]; L.diee_train_colsum.restype = C.c_int
     L.diee_train_wgrad_scratch_floats.argtypes = []; L.diee_train_wgrad_scratch_floats.restype = C.c_size_t
     L.diee_train_wgrad3x3.argtypes = [vp, vp, vp, C.c_int, vp, vp]; L.diee_train_wgrad3x3.restype = C.c_int

@@ -241,7 +241,7 @@ diee_status diee_train_im2col3x3(const void* x, void* col, int boards, void* str
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
 
-size_t diee_train_scratch_floats(int rows) { return (size_t)train_stripes(rows) * 512 + 1280; }   // partials + the apply pass's coefficients
+size_t diee_train_scratch_floats(int rows) { return (size_t)train_stripes(rows) * 768 + 1280; }   // partials + the apply pass's coefficients
 diee_status diee_train_bn_relu_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* run_mean,
                                    float* run_var, float momentum, float eps, float* save_mean, float* save_invstd, void* y, int rows,
                                    float* scratch, void* stream) {
@@ -251,11 +251,11 @@ diee_status diee_train_bn_relu_fwd(const void* x, const void* res, const float* 
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
 diee_status diee_train_bn_relu_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                                   const float* save_invstd, float* dgamma, float* dbeta, void* dx, void* dres, int rows,
-                                   float* scratch, void* stream) {
+                                   const float* save_invstd, float* dgamma, float* dbeta, void* dx, void* dres, float* dx_colsum,
+                                   int rows, float* scratch, void* stream) {
     if (!dy || !y || !x || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dx || !scratch || rows <= 0) return DIEE_ERR_ARG;
     launch_bn_relu_bwd((hipStream_t)stream, (const uint16_t*)dy, (const uint16_t*)y, (const uint16_t*)x, gamma, save_mean, save_invstd,
-                       scratch, dgamma, dbeta, (uint16_t*)dx, (uint16_t*)dres, rows);
+                       scratch, dgamma, dbeta, (uint16_t*)dx, (uint16_t*)dres, dx_colsum, rows);
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
 size_t diee_train_wgrad_scratch_floats(void) { return wgrad_scratch_floats(); }

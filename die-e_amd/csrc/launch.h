@@ -35,14 +35,14 @@ constexpr int kClusterMaxGroups = 64;
 // `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
-// train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 512 floats of scratch)
+// train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 768 + 1280 floats of scratch)
 int train_stripes(int M);
 void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,
                         float* save_mean, float* save_invstd, float* run_mean, float* run_var, float momentum, float eps,
                         uint16_t* y, int M);
 void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
                         const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
-                        uint16_t* dres, int M);
+                        uint16_t* dres, float* dx_colsum /*[256] or nullptr*/, int M);
 size_t wgrad_scratch_floats();
 void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards);
 void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);

@@ -7,6 +7,7 @@
 // order): deterministic, no atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "launch.h"
 
@@ -190,13 +191,309 @@ __global__ __launch_bounds__(1024) void k_colsum_final(const float* __restrict__
     if (threadIdx.x < 256) out[threadIdx.x] = s;
 }
 
+// ---- single-launch BatchNorm passes -------------------------------------------------------------------------------
+// The three launches above move 3 MB each and run 5-8 us apiece, almost all of it launch latency.  When every stripe's
+// workgroup can be resident at once (stripes <= resident workgroups: the launcher checks, 96 at batch 256) one launch does the
+// whole pass: a workgroup of 1024 threads keeps its 64-row stripe in registers, publishes its partial sums with
+// device-coherent stores, meets the other workgroups on a counter, folds ALL partials itself in the fixed order (every
+// workgroup computes the same statistics, bit for bit), and applies them to the registers it still holds.
+// The meeting is bounded: a workgroup that waits too long stops waiting and poisons its statistics with NaN, so a starved
+// launch is loud in the loss instead of hanging the device.
+#ifndef DIEE_BN_ABLATE
+#define DIEE_BN_ABLATE 0      // dev builds: 1 = fold one stripe per part only, 2 = no meeting (both compute garbage)
+#endif
+constexpr int kBnSpinLimit = 1 << 18;               // x s_sleep(2) ~ 128 cycles: tens of milliseconds
+#define DIEE_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, DIEE_AGENT); }
+__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, DIEE_AGENT); }
+
+// bar[0] arrivals (back to 0 when the last one arrives), bar[1] generation.  All threads call; returns false on a timeout.
+__device__ __forceinline__ bool grid_meet(uint32_t* bar, unsigned n) {
+    __shared__ int ok_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's coherent stores are acknowledged
+    __syncthreads();
+#if DIEE_BN_ABLATE == 2
+    return true;
+#endif
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const uint32_t gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, DIEE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the generation is read before this arrival counts
+        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, DIEE_AGENT) == n - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, DIEE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, DIEE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, DIEE_AGENT) == gen) {
+                if (++spins > kBnSpinLimit) { ok = 0; __hip_atomic_fetch_or(bar + 3, 1u, __ATOMIC_RELAXED, DIEE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+// sums over the stripe's rows of s0 / s1 (8 channels per thread, thread t: channels 8*(t & 31).., row slot t >> 5 of 32):
+// the two half-waves meet by a cross-lane add, the 16 waves through LDS; threads 0..255 return the totals of channel t
+__device__ __forceinline__ void stripe_reduce(float (&s0)[8], float (&s1)[8], float (*red)[16][256], float& x0, float& x1) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] += __shfl_xor(s0[j], 32); s1[j] += __shfl_xor(s1[j], 32); }
+    __syncthreads();                                            // red may still be read by the previous reduction
+    if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][wave][lane * 8 + j] = s0[j]; red[1][wave][lane * 8 + j] = s1[j]; }
+    }
+    __syncthreads();
+    x0 = 0.f; x1 = 0.f;
+    if (t < 256) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { x0 += red[0][k][t]; x1 += red[1][k][t]; }
+    }
+}
+
+// fold_partials over device-coherent loads, for the launches whose partials were written by this very launch
+__device__ __forceinline__ void fold_partials_coh(const float* partial, int stripes, int nq, float& q0, float& q1) {
+    __shared__ float acc[2][4][256];
+    const int c = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const int per = (stripes + 3) / 4, s0 = part * per;
+    int s1 = s0 + per < stripes ? s0 + per : stripes;
+    // 16 stripes' loads in flight at a time (a coherent load is a round trip past the L2), added in stripe order
+    float a[2] = {0.f, 0.f}, b[2] = {0.f, 0.f};
+#if DIEE_BN_ABLATE == 1
+    if (s1 > s0 + 1) s1 = s0 + 1;
+#endif
+    for (int s = s0; s < s1; s += 16) {
+        float va[16], vb[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int ss = s + k < s1 ? s + k : s1 - 1;
+            va[k] = ld_coh(partial + ((size_t)ss * nq + 0) * 256 + c);
+            vb[k] = nq == 2 ? ld_coh(partial + ((size_t)ss * nq + 1) * 256 + c) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (s + k < s1) { a[k & 1] += va[k]; b[k & 1] += vb[k]; }
+    }
+    __syncthreads();
+    acc[0][part][c] = a[0] + a[1]; acc[1][part][c] = b[0] + b[1];
+    __syncthreads();
+    q0 = (acc[0][0][c] + acc[0][1][c]) + (acc[0][2][c] + acc[0][3][c]);
+    q1 = (acc[1][0][c] + acc[1][1][c]) + (acc[1][2][c] + acc[1][3][c]);
+}
+
+__global__ __launch_bounds__(1024) void k_bn_fwd_coop(const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* partial, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                     float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                     float eps, uint16_t* __restrict__ y, int M, uint32_t* bar) {
+    __shared__ float red[2][16][256];
+    __shared__ float coef[2][256];
+    const int t = threadIdx.x, c8 = t & 31, rs = t >> 5, row_lo = blockIdx.x * kStripe, S = gridDim.x;
+    tu32x4 xv[2], rv[2];
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = row_lo + rs + 32 * k;
+        xv[k] = tu32x4{0u, 0u, 0u, 0u}; rv[k] = tu32x4{0u, 0u, 0u, 0u};
+        if (r < M) {
+            xv[k] = *(const tu32x4*)(x + (size_t)r * 256 + c8 * 8);
+            if (res) rv[k] = *(const tu32x4*)(res + (size_t)r * 256 + c8 * 8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float v[8];
+        unpack8(xv[k], v);                                      // rows past M hold zeros: they add nothing
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += v[j]; s1[j] += v[j] * v[j]; }
+    }
+    float p0, p1;
+    stripe_reduce(s0, s1, red, p0, p1);
+    if (t < 256) { st_coh(partial + ((size_t)blockIdx.x * 2 + 0) * 256 + t, p0); st_coh(partial + ((size_t)blockIdx.x * 2 + 1) * 256 + t, p1); }
+    const bool ok = grid_meet(bar, S);
+    float sum, sq;
+    fold_partials_coh(partial, S, 2, sum, sq);
+    if (t < 256) {
+        float mean = sum / (float)M;
+        float var = sq / (float)M - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float is = 1.0f / sqrtf(var + eps);
+        if (!ok) mean = __builtin_nanf("");
+        coef[0][t] = gamma[t] * is; coef[1][t] = beta[t] - mean * gamma[t] * is;
+        if (blockIdx.x == 0) {
+            save_mean[t] = mean; save_invstd[t] = is;
+            if (run_mean) {
+                const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+                run_mean[t] = (1.f - momentum) * run_mean[t] + momentum * mean;
+                run_var[t] = (1.f - momentum) * run_var[t] + momentum * unb;
+            }
+        }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = coef[0][c8 * 8 + j]; sh[j] = coef[1][c8 * 8 + j]; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = row_lo + rs + 32 * k;
+        if (r >= M) continue;
+        float v[8], rr[8];
+        unpack8(xv[k], v); unpack8(rv[k], rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            if (res) z += rr[j];
+            v[j] = z > 0.f ? z : 0.f;
+        }
+        *(tu32x4*)(y + (size_t)r * 256 + c8 * 8) = pack8(v);
+    }
+}
+
+// backward in one launch; with dx_colsum also the column sums of the (bf16-rounded) dx it writes -- the bias gradient of
+// the convolution in front -- from a second round of partials that only workgroup 0 waits for (bar[2] counts them)
+__global__ __launch_bounds__(1024) void k_bn_bwd_coop(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ y,
+                                                     const uint16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     float* partial, float* partial2, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, uint16_t* __restrict__ dx,
+                                                     uint16_t* __restrict__ dres, float* __restrict__ dx_colsum, int M, uint32_t* bar) {
+    __shared__ float red[2][16][256];
+    __shared__ float coef[3][256];
+    const int t = threadIdx.x, c8 = t & 31, rs = t >> 5, row_lo = blockIdx.x * kStripe, S = gridDim.x;
+    tu32x4 gv[2], yv[2], xv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = row_lo + rs + 32 * k;
+        gv[k] = tu32x4{0u, 0u, 0u, 0u}; yv[k] = gv[k]; xv[k] = gv[k];
+        if (r < M) {
+            gv[k] = *(const tu32x4*)(dy + (size_t)r * 256 + c8 * 8);
+            yv[k] = *(const tu32x4*)(y + (size_t)r * 256 + c8 * 8);
+            xv[k] = *(const tu32x4*)(x + (size_t)r * 256 + c8 * 8);
+        }
+    }
+    float mu[8], is[8], s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = mean[c8 * 8 + j]; is[j] = invstd[c8 * 8 + j]; s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float g[8], yy[8], xx[8];
+        unpack8(gv[k], g); unpack8(yv[k], yy); unpack8(xv[k], xx);      // rows past M: y = 0 masks them out
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dz = yy[j] > 0.f ? g[j] : 0.f;
+            s0[j] += dz; s1[j] += dz * ((xx[j] - mu[j]) * is[j]);
+        }
+    }
+    float p0, p1;
+    stripe_reduce(s0, s1, red, p0, p1);
+    if (t < 256) { st_coh(partial + ((size_t)blockIdx.x * 2 + 0) * 256 + t, p0); st_coh(partial + ((size_t)blockIdx.x * 2 + 1) * 256 + t, p1); }
+    const bool ok = grid_meet(bar, S);
+    float sdz, sdzx;
+    fold_partials_coh(partial, S, 2, sdz, sdzx);
+    if (t < 256) {
+        if (!ok) sdz = __builtin_nanf("");
+        if (blockIdx.x == 0) { dgamma[t] = sdzx; dbeta[t] = sdz; }
+        coef[0][t] = gamma[t] * invstd[t]; coef[1][t] = sdz / (float)M; coef[2][t] = sdzx / (float)M;
+    }
+    __syncthreads();
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k0[j] = coef[0][c8 * 8 + j]; k1[j] = coef[1][c8 * 8 + j]; k2[j] = coef[2][c8 * 8 + j]; s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = row_lo + rs + 32 * k;
+        if (r >= M) continue;
+        float g[8], yy[8], xx[8], dz[8];
+        unpack8(gv[k], g); unpack8(yv[k], yy); unpack8(xv[k], xx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dz[j] = yy[j] > 0.f ? g[j] : 0.f;
+            const float xh = (xx[j] - mu[j]) * is[j];
+            g[j] = k0[j] * (dz[j] - k1[j] - xh * k2[j]);
+        }
+        const tu32x4 o = pack8(g);
+        *(tu32x4*)(dx + (size_t)r * 256 + c8 * 8) = o;
+        if (dres) *(tu32x4*)(dres + (size_t)r * 256 + c8 * 8) = pack8(dz);
+        if (dx_colsum) {
+            float q[8];
+            unpack8(o, q);                                      // the sum of what was written, like a pass over dx would see it
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s0[j] += q[j];
+        }
+    }
+    if (!dx_colsum) return;
+    stripe_reduce(s0, s1, red, p0, p1);
+    if (t < 256) st_coh(partial2 + (size_t)blockIdx.x * 256 + t, p0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int ok2_s;
+    if (t == 0) {
+        __hip_atomic_fetch_add(bar + 2, 1u, __ATOMIC_RELAXED, DIEE_AGENT);
+        int ok2 = 1;
+        if (blockIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, DIEE_AGENT) != (uint32_t)S) {
+                if (++spins > kBnSpinLimit) { ok2 = 0; __hip_atomic_fetch_or(bar + 3, 2u, __ATOMIC_RELAXED, DIEE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __hip_atomic_store(bar + 2, 0u, __ATOMIC_RELAXED, DIEE_AGENT);
+        }
+        ok2_s = ok2;
+    }
+    if (blockIdx.x != 0) return;
+    __syncthreads();
+    float cs, unused;
+    fold_partials_coh(partial2, S, 1, cs, unused);
+    if (t < 256) dx_colsum[t] = ok2_s ? cs : __builtin_nanf("");
+}
+
+// four words per device: the counters of grid_meet (and the timeout flags); how many 1024-thread workgroups fit at once
+static uint32_t* bn_sync_words(int& resident) {
+    static uint32_t* w[16] = {nullptr};
+    static int res[16] = {0};
+    int dev = 0;
+    resident = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!w[dev]) {
+        uint32_t* p = nullptr;
+        if (hipMalloc((void**)&p, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+        int per_cu_f = 0, per_cu_b = 0, cus = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void*)k_bn_fwd_coop, 1024, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)k_bn_bwd_coop, 1024, 0);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        res[dev] = (per_cu_f > 0 && per_cu_b > 0) ? cus : 0;     // one workgroup per CU is all the launcher counts on
+        w[dev] = p;
+    }
+    resident = res[dev];
+    return w[dev];
+}
+static bool bn_coop_enabled() {
+    static const bool on = [] { const char* e = getenv("DIEE_BN_COOP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int train_stripes(int M) { return (M + kStripe - 1) / kStripe; }
 
+void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);
 void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,
                         float* save_mean, float* save_invstd, float* run_mean, float* run_var, float momentum, float eps,
                         uint16_t* y, int M) {
     const int S = train_stripes(M);
-    float* coef = partial + (size_t)S * 512;
+    float* coef = partial + (size_t)S * 768;
+    int resident = 0;
+    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(resident) : nullptr;
+    if (bar && S <= resident) {
+        hipLaunchKernelGGL(k_bn_fwd_coop, dim3(S), dim3(1024), 0, st, x, res, gamma, beta, partial, save_mean, save_invstd, run_mean,
+                           run_var, momentum, eps, y, M, bar);
+        return;
+    }
     hipLaunchKernelGGL((k_col_partials<false>), dim3(S), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, partial, M);
     hipLaunchKernelGGL(k_bn_stats, dim3(1), dim3(1024), 0, st, partial, S, gamma, beta, save_mean, save_invstd, run_mean, run_var,
                        momentum, eps, coef, M);
@@ -204,12 +501,20 @@ void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, 
 }
 void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
                         const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
-                        uint16_t* dres, int M) {
+                        uint16_t* dres, float* dx_colsum, int M) {
     const int S = train_stripes(M);
-    float* coef = partial + (size_t)S * 512;
+    float* coef = partial + (size_t)S * 768;
+    int resident = 0;
+    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(resident) : nullptr;
+    if (bar && S <= resident) {
+        hipLaunchKernelGGL(k_bn_bwd_coop, dim3(S), dim3(1024), 0, st, dy, y, x, gamma, mean, invstd, partial, partial + (size_t)S * 512,
+                           dgamma, dbeta, dx, dres, dx_colsum, M, bar);
+        return;
+    }
     hipLaunchKernelGGL((k_col_partials<true>), dim3(S), dim3(256), 0, st, dy, x, y, mean, invstd, partial, M);
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(1), dim3(1024), 0, st, partial, S, gamma, mean, invstd, dgamma, dbeta, coef, M);
     hipLaunchKernelGGL(k_bn_relu_bwd, dim3(S), dim3(256), 0, st, dy, y, x, coef, dx, dres, M);
+    if (dx_colsum) launch_colsum(st, dx, partial, dx_colsum, M);
 }
 void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M) {
     const int S = train_stripes(M);
@@ -233,7 +538,14 @@ void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out
 typedef __attribute__((ext_vector_type(8))) __bf16 wbf16x8;
 typedef __attribute__((ext_vector_type(16))) float wf32x16;
 typedef short wv4s __attribute__((ext_vector_type(4)));
-constexpr int kWgBoards = 16, kWgRows = kWgBoards * 24, kWgHalo = 8, kWgRS = 192, kWgSplit = 16;
+constexpr int kWgBoards = 16, kWgRows = kWgBoards * 24, kWgHalo = 8, kWgRS = 192;
+#ifndef DIEE_WG_SPLIT
+#define DIEE_WG_SPLIT 16
+#endif
+constexpr int kWgSplit = DIEE_WG_SPLIT;
+#ifndef DIEE_WG_ABLATE
+#define DIEE_WG_ABLATE 0
+#endif
 constexpr int kWgXBytes = (kWgRows + 2 * kWgHalo) * kWgRS, kWgYBytes = kWgRows * kWgRS;
 
 // 8 consecutive rows (k) x 32 columns of an LDS image [row][64 columns], as the 32x32x16 MFMA operand of lane `lane`:
@@ -322,13 +634,13 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(const uint16_t* __restrict__ x
         for (int k = 0; k < kXv; ++k) {
             const int i = tid + k * 512, r = i >> 3, ch = i & 7, gr = row_base + r - kWgHalo;
             vx[k] = tu32x4{0u, 0u, 0u, 0u};
-            if (r < kWgRows + 2 * kWgHalo && gr >= 0 && gr < M) vx[k] = *(const tu32x4*)(x + (size_t)gr * 256 + cb * 64 + ch * 8);
+            if (DIEE_WG_ABLATE != 3 && r < kWgRows + 2 * kWgHalo && gr >= 0 && gr < M) vx[k] = *(const tu32x4*)(x + (size_t)gr * 256 + cb * 64 + ch * 8);
         }
 #pragma unroll
         for (int k = 0; k < kYv; ++k) {
             const int i = tid + k * 512, r = i >> 3, ch = i & 7, gr = row_base + r;
             vy[k] = tu32x4{0u, 0u, 0u, 0u};
-            if (gr < M) vy[k] = *(const tu32x4*)(dy + (size_t)gr * 256 + nb * 64 + ch * 8);
+            if (DIEE_WG_ABLATE != 3 && gr < M) vy[k] = *(const tu32x4*)(dy + (size_t)gr * 256 + nb * 64 + ch * 8);
         }
 #pragma unroll
         for (int k = 0; k < kXv; ++k) {
@@ -341,10 +653,15 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(const uint16_t* __restrict__ x
             *(tu32x4*)(ys + r * kWgRS + ch * 16) = vy[k];
         }
         __syncthreads();
+#if DIEE_WG_ABLATE != 2
         if (ntaps == 5) wgrad_slice<5>(xs, ys, ct, nt, lane, shift, mk, acc);
         else wgrad_slice<4>(xs, ys, ct, nt, lane, shift, mk, acc);
+#endif
     }
     // C/D layout of 32x32: column (n) = lane & 31, rows (c) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+#if DIEE_WG_ABLATE == 1
+    if (M != 12345) return;
+#endif
 #pragma unroll
     for (int ti = 0; ti < 5; ++ti) {
         if (ti >= ntaps) break;

@@ -39,6 +39,9 @@ def _chk(st, what):
         raise RuntimeError(f"{what} failed with diee status {st}")
 
 
+_dx_colsum = [None, None]              # (data_ptr of the dx a batch-norm backward just wrote, its column sums): the conv bias gradient
+
+
 class Conv3x3Tok(torch.autograd.Function):
     """y[M,256] = conv3x3 over 4x6 boards of x[M,256] (M = boards*24, bf16) with w[256,256,3,3] (fp32) + b[256] (fp32)"""
 
@@ -82,7 +85,10 @@ class Conv3x3Tok(torch.autograd.Function):
                 dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
                 scratch = torch.empty(int(L.diee_train_wgrad_scratch_floats()), dtype=torch.float32, device=x.device)
                 _chk(L.diee_train_wgrad3x3(_ptr(x), _ptr(dy), _ptr(dw), boards, _ptr(scratch), _stream()), "wgrad")
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and _dx_colsum[0] == dy.data_ptr():
+            db = _dx_colsum[1]                                   # the batch-norm backward that wrote dy summed its columns already
+            _dx_colsum[0] = _dx_colsum[1] = None
+        elif ctx.needs_input_grad[2]:
             db = torch.empty(256, dtype=torch.float32, device=x.device)
             scratch = torch.empty(int(L.diee_train_scratch_floats(x.shape[0])), dtype=torch.float32, device=x.device)
             _chk(L.diee_train_colsum(_ptr(dy), _ptr(db), x.shape[0], _ptr(scratch), _stream()), "colsum")
@@ -122,9 +128,12 @@ class BnReluTok(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         dgamma = torch.empty(256, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+        colsum = torch.empty_like(dgamma)
         scratch = torch.empty(int(L.diee_train_scratch_floats(M)), dtype=torch.float32, device=x.device)
         _chk(L.diee_train_bn_relu_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
-                                      _ptr(dx), _ptr(dres) if dres is not None else None, M, _ptr(scratch), _stream()), "bn_relu backward")
+                                      _ptr(dx), _ptr(dres) if dres is not None else None, _ptr(colsum), M, _ptr(scratch), _stream()),
+             "bn_relu backward")
+        _dx_colsum[0], _dx_colsum[1] = dx.data_ptr(), colsum     # for the backward of the convolution in front (next in autograd order)
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 

@@ -197,7 +197,10 @@ diee_status diee_train_conv3x3(const void* x_bf16, const void* wpack, const floa
 diee_status diee_train_im2col3x3(const void* x_bf16, void* col_bf16 /*[boards*24][2304]*/, int boards, void* stream);
 /* BatchNorm2d in training mode over the rows (= batch x 4 x 6) fused with the residual add and the ReLU of
  * ResBlock::forward_t (nnet.rs:24-34): y = relu(gamma * (x - mean) / sqrt(var + eps) + beta [+ res]); updates the running
- * statistics (momentum, unbiased variance) when given.  scratch: diee_train_scratch_floats(rows) floats.  Deterministic. */
+ * statistics (momentum, unbiased variance) when given.  scratch: diee_train_scratch_floats(rows) floats.  Deterministic.
+ * Each pass is ONE launch while rows / 64 workgroups can be resident together (they meet on a device counter: do not run two
+ * of these passes concurrently on different streams of one device), three launches above that or with DIEE_BN_COOP=0.
+ * dx_colsum, when given, receives the column sums of dx: the bias gradient of the convolution that produced x. */
 size_t      diee_train_scratch_floats(int rows);
 diee_status diee_train_bn_relu_fwd(const void* x_bf16, const void* res_bf16 /*or NULL*/, const float* gamma, const float* beta,
                                    float* running_mean /*or NULL*/, float* running_var, float momentum, float eps,
@@ -206,7 +209,8 @@ diee_status diee_train_bn_relu_fwd(const void* x_bf16, const void* res_bf16 /*or
 /* its backward: dx (to the convolution), dres (= dy masked by the ReLU, to the skip connection; may be NULL), dgamma, dbeta */
 diee_status diee_train_bn_relu_bwd(const void* dy_bf16, const void* y_bf16, const void* x_bf16, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                                   void* dx_bf16, void* dres_bf16, int rows, float* scratch, void* stream);
+                                   void* dx_bf16, void* dres_bf16 /*or NULL*/, float* dx_colsum /*[256] or NULL*/, int rows,
+                                   float* scratch, void* stream);
 /* weight gradient of the tower convolution, hand-written: dW[n][c][ky][kx] (fp32, OIHW) = sum over rows of
  * x[row + shift(ky,kx)][c] * dy[row][n]; scratch: diee_train_wgrad_scratch_floats() floats.  Deterministic. */
 size_t      diee_train_wgrad_scratch_floats(void);

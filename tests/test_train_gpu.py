@@ -67,7 +67,8 @@ def test_fused_bn_relu_matches_pytorch_batch_norm():
     import torch.nn.functional as Fn
     ops = importlib.import_module("die-e_amd.train_ops")
     torch.manual_seed(3)
-    for M, with_res in ((6144, True), (6144, False), (24 * 5, True)):
+    # 24 * 700 rows = 263 stripes: more than one workgroup per CU, the three-launch passes; the others run the one-launch passes
+    for M, with_res in ((6144, True), (6144, False), (24 * 5, True), (24 * 700, True), (24 * 77 + 0, False)):
         x = (torch.randn(M, 256, device="cuda") * 1.7 + 0.3).to(torch.bfloat16).requires_grad_(True)
         res = torch.randn(M, 256, device="cuda").to(torch.bfloat16).requires_grad_(True) if with_res else None
         gamma = torch.rand(256, device="cuda").requires_grad_(True); beta = (torch.randn(256, device="cuda") * 0.1).requires_grad_(True)
@@ -86,6 +87,52 @@ def test_fused_bn_relu_matches_pytorch_batch_norm():
         errs = [rel(a.float(), b) for a, b in zip(outs, refs)]
         print(f"[train-parity] bn_relu M={M} res={with_res}: forward {rel(y.float(), yr):.2e}  dx {errs[0]:.2e}  dgamma {errs[1]:.2e}  dbeta {errs[2]:.2e}" + (f"  dres {errs[3]:.2e}" if with_res else ""))
         assert all(e < 1e-2 for e in errs)
+        # the pass also leaves the column sums of the dx it wrote (the bias gradient of the convolution in front): equal to
+        # summing the bf16 dx afterwards, up to the fp32 summation order
+        ptr, colsum = ops._dx_colsum
+        assert ptr == outs[0].data_ptr()
+        want = outs[0].double().sum(0)
+        assert float((colsum.double() - want).abs().max()) <= 1e-4 * float(outs[0].double().abs().sum(0).max()) + 1e-6
+        ops._dx_colsum[0] = ops._dx_colsum[1] = None
+
+
+def test_one_launch_batch_norm_equals_the_three_launch_passes():
+    """DIEE_BN_COOP: the single-launch passes (workgroups meet on a device counter) and the three-launch passes compute the
+    same statistics from the same partial sums in a different order: outputs equal to rounding, and the one-launch pass is
+    deterministic run to run"""
+    import os, subprocess, sys, json
+    code = r"""
+import importlib, json, sys, torch
+ops = importlib.import_module("die-e_amd.train_ops")
+torch.manual_seed(11)
+M = 6144
+x = (torch.randn(M, 256, device="cuda") * 1.3).to(torch.bfloat16).requires_grad_(True)
+res = torch.randn(M, 256, device="cuda").to(torch.bfloat16).requires_grad_(True)
+g = torch.rand(256, device="cuda").requires_grad_(True); b = torch.randn(256, device="cuda").requires_grad_(True)
+dy = torch.randn(M, 256, device="cuda").to(torch.bfloat16)
+outs = []
+for rep in range(3):
+    rm, rv = torch.zeros(256, device="cuda"), torch.ones(256, device="cuda")
+    y = ops.BnReluTok.apply(x, g, b, res, rm, rv, 0.1, 1e-5)
+    gr = torch.autograd.grad(y, (x, g, b, res), dy)
+    outs.append([y.detach().float().cpu(), rm.cpu(), rv.cpu()] + [t.float().cpu() for t in gr] + [ops._dx_colsum[1].cpu()])
+for o in outs[1:]:
+    assert all(torch.equal(a, c) for a, c in zip(o, outs[0])), "not deterministic"
+torch.save(outs[0], sys.argv[1])
+"""
+    import tempfile, torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    with tempfile.TemporaryDirectory() as d:
+        for coop in ("1", "0"):
+            env = dict(os.environ, DIEE_BN_COOP=coop, PYTHONPATH=root)
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, coop + ".pt")], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got[coop] = torch.load(os.path.join(d, coop + ".pt"))
+    assert float((got["1"][-1] - got["0"][-1]).abs().max()) < 1e-3 * float(got["0"][3].abs().sum(0).max())    # column sums of dx: sums of rounding errors
+    for a, c in zip(got["1"][:-1], got["0"][:-1]):
+        assert rel(a, c) < 2e-3                                      # bf16 outputs may differ by an ulp where the statistics' last bit differs
+    assert rel(got["1"][1], got["0"][1]) < 1e-5 and rel(got["1"][2], got["0"][2]) < 1e-5      # running statistics (fp32)
 
 
 def test_training_step_on_engine_kernels_tracks_the_fp32_step(oracle):
