@@ -13,6 +13,12 @@ import secrets
 import time
 
 import numpy as np
+
+# the init block and the two head convolutions stay in PyTorch (MIOpen): its default exhaustive solver search costs 5.3 s on
+# the first training step of a process (naive reference kernels included) against 0.7 s with the heuristic pick, for three
+# convolutions that are 2 % of the step.  The user's own setting wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import torch
 
 from . import BG_ACTIONS, BG_PLANES, Engine, MctsConfig, random_weights
@@ -330,7 +336,9 @@ class AlphaZero:
         self._graph = g
         return g
 
-    def train(self, memory, rng=None):
+    def train(self, memory, rng=None, resident=False):
+        """resident=True: `memory` is the one the previous call uploaded (the learn loop's epochs 2..n over one memory):
+        only the new permutation travels to the device"""
         import torch
         n = len(memory["outcome"])
         rng = rng or self.shuffle_rng                                           # a fresh permutation every call (every epoch)
@@ -364,10 +372,14 @@ class AlphaZero:
                              "oc": torch.empty(cap, device=self.device), "perm": torch.empty(cap, dtype=torch.int64, device=self.device),
                              "loss": torch.zeros(-(-cap // max(bs, 1)) + 1, device=self.device)}
                 self._mem_cap = cap
+                self._mem_n = -1
                 torch.cuda.synchronize()
             M = self._mem
-            M["st"][:n].copy_(torch.from_numpy(memory["state"])); M["ps"][:n].copy_(torch.from_numpy(memory["ps"]))
-            M["oc"][:n].copy_(torch.from_numpy(memory["outcome"].astype(np.float32))); M["perm"][:n].copy_(torch.from_numpy(perm))
+            if not (resident and getattr(self, "_mem_n", -1) == n):             # 2.6 GB of pageable host memory per upload: once per memory
+                M["st"][:n].copy_(torch.from_numpy(memory["state"])); M["ps"][:n].copy_(torch.from_numpy(memory["ps"]))
+                M["oc"][:n].copy_(torch.from_numpy(memory["outcome"].astype(np.float32)))
+                self._mem_n = n
+            M["perm"][:n].copy_(torch.from_numpy(perm))
             mem_st, mem_ps, mem_oc, perm_t = M["st"], M["ps"], M["oc"], M["perm"]
             loss_buf = M["loss"] if len(M["loss"]) >= n_steps else torch.zeros(max(n_steps, 1), device=self.device)
         else:
@@ -442,8 +454,8 @@ class AlphaZero:
             mem = self.concat(memory)
             t_tr = time.time()
             losses = []
-            for _ in range(self.config.num_epochs):                             # :78-81
-                losses += self.train(mem)
+            for ep in range(self.config.num_epochs):                            # :78-81
+                losses += self.train(mem, resident=ep > 0)
             self.sync_engine()
             t_tr = time.time() - t_tr
             if self.rank == 0:
