@@ -48,7 +48,7 @@ EXPORTS = [
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
     "diee_bg_planes", "diee_det_pow",
 ]
-DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench"]
+DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench", "diee_dev_wave_selftest"]
 
 
 class DieeError(RuntimeError):
@@ -147,6 +147,7 @@ def load_library(path=None):
     L.diee_probe_dice.argtypes = [vp, u64, vp, u32, vp, vp]; L.diee_probe_dice.restype = C.c_int
     L.diee_dev_conv_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]; L.diee_dev_conv_bench.restype = C.c_int
     L.diee_dev_rules_bench.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp]; L.diee_dev_rules_bench.restype = C.c_int
+    L.diee_dev_wave_selftest.argtypes = [vp, C.c_uint32, vp]; L.diee_dev_wave_selftest.restype = C.c_int
     if path is None:
         _lib = L
     return L
@@ -285,6 +286,12 @@ class Engine:
         us, k = C.c_float(0), C.c_float(0)
         self._chk(self._L.diee_dev_rules_bench(self._h, s.ctypes.data, len(s), reps, C.byref(us), C.byref(k)))
         return us.value, k.value
+
+    def wave_selftest(self, salt=0):
+        """csrc/wave_ops.h against the shuffles it replaces: number of disagreeing lanes x cases (0 = correct)"""
+        bad = C.c_uint32(0)
+        self._chk(self._L.diee_dev_wave_selftest(self._h, salt, C.byref(bad)))
+        return int(bad.value)
 
     # ---- search ------------------------------------------------------------------------------
     def set_invariant_nn(self, on=True):

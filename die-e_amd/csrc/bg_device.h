@@ -6,6 +6,7 @@
 // 24-bit occupancy masks (ballots), one lane per first move, an LDS sequence table, and a
 // first-occurrence-wins dedup on an exact 128-bit board-delta key.
 #pragma once
+#include "wave_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -190,13 +191,8 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
         nseq = cm ? __popc(cm) : 1;                              // :740-741 childless root = 1-move play
     }
     // exclusive prefix sum of nseq over lanes
-    int incl = nseq;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    const int S = __shfl(incl, 63);
+    const int incl = wave_inclusive_scan_i32(nseq);         // DPP row scans + row broadcasts (wave_ops.h), no LDS-pipe shuffles
+    const int S = __builtin_amdgcn_readlane(incl, 63);
     const int base = incl - nseq;
     if (S > kSeqCap) { if (lane == 0) atomicOr(overflow, 1u); return 0; }
 

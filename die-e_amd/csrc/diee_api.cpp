@@ -205,6 +205,18 @@ diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint3
     API_END(c)
 }
 
+diee_status diee_dev_wave_selftest(diee_ctx* c, uint32_t salt, uint32_t* mismatches) {
+    API_BEGIN(c)
+    if (!mismatches) throw EngineError(DIEE_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    c->tmp_c.ensure(4);
+    HIPCHK(hipMemsetAsync(c->tmp_c.p, 0, 4, c->stream));
+    launch_wave_selftest(c->stream, (uint32_t*)c->tmp_c.p, salt);
+    c->d2h((uint8_t*)mismatches, c->tmp_c.p, 4);
+    c->sync();
+    API_END(c)
+}
+
 // ---- training-step kernels: stateless, on the caller's stream ----
 static const float* zero_bias256() {
     static float* z[16] = {nullptr};                             // one 1 KB allocation per device the process trains on

@@ -12,6 +12,7 @@
 #include "nn_device.h"
 #include "launch.h"
 #include "search_types.h"
+#include "wave_ops.h"
 
 namespace diee {
 
@@ -41,6 +42,15 @@ __device__ __forceinline__ void backprop(const Tree& T, size_t base, uint32_t id
     }
 }
 
+// the same update for a selection whose root-to-leaf nodes were recorded (entry d = depth d): lane d updates its node,
+// one round of memory latency instead of one per level.  Every node is touched once, by one lane: the same bits.
+__device__ __forceinline__ void backprop_path(const Tree& T, size_t base, uint32_t my_node, int lane, uint32_t len, float v) {
+    if ((uint32_t)lane < len) {
+        T.visits[base + my_node] += 1.0f;
+        T.value[base + my_node] += v;
+    }
+}
+
 // ---- roots -------------------------------------------------------------------------------------
 // alpha_mcts.rs:110-112,123: one root node per state, visits = 1
 __global__ void k_init_roots(Tree T, Slots S, uint32_t n) {
@@ -53,7 +63,8 @@ __global__ void k_init_roots(Tree T, Slots S, uint32_t n) {
     T.visits[base] = 1.0f; T.value[base] = 0.0f; T.prior[base] = 0.0f;
     T.parent[base] = kNone; T.first_child[base] = 0; T.meta[base] = 0xFFFFu;
     T.used[slot] = 1;
-    S.sel[slot] = kNone; S.sel_value[slot] = 0.0f; S.leaf[slot] = 0; S.leaf_term[slot] = 0;
+    S.sel[slot] = kNone; S.sel_value[slot] = 0.0f; S.leaf[slot] = 0; S.leaf_term[slot] = 0; S.path_len[slot] = 0;
+    S.leaf_meta[slot] = 0xFFFFu;
 #pragma unroll
     for (int c = 0; c < SC_COUNT; ++c) S.slot_cnt[slot * SC_COUNT + c] = 0;
 }
@@ -67,36 +78,63 @@ __device__ __forceinline__ Best better(Best a, Best b) {      // later index win
     return b;
 }
 
+// the best of the wave in every lane; `better` is a symmetric total order, so the pairing order is free (wave_ops.h)
+__device__ __forceinline__ Best wave_best(Best b) {
+    Best o;
+    o.s = dpp_f32<kDppXor1>(b.s); o.j = dpp_i32<kDppXor1>(b.j); b = better(b, o);
+    o.s = dpp_f32<kDppXor2>(b.s); o.j = dpp_i32<kDppXor2>(b.j); b = better(b, o);
+    o.s = dpp_f32<kDppHalfMirror>(b.s); o.j = dpp_i32<kDppHalfMirror>(b.j); b = better(b, o);
+    o.s = dpp_f32<kDppMirror>(b.s); o.j = dpp_i32<kDppMirror>(b.j); b = better(b, o);
+    const int si = __builtin_bit_cast(int, b.s);
+    Best r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r[q].s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(si, 16 * q));
+        r[q].j = __builtin_amdgcn_readlane(b.j, 16 * q);
+    }
+    return better(better(r[0], r[1]), better(r[2], r[3]));
+}
+
 // alpha_select_leaf_node / select_alpha (alpha_mcts.rs:14-33) with alpha_ucb (node.rs:98-112):
 //   q + (c * (sqrt(N_parent) / (n + 1))) * p, f32, in this association; NaN compares Equal.
-__device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t slot, int lane, uint32_t it,
-                                            float c, uint32_t quirks) {
+// One memory round trip per level: a level reads the statistics of all children AND their headers (meta, first child), so
+// the chosen child's header is already in a register of the lane that scored it (a wave alone on its SIMD waits out every
+// round trip: header -> children -> header -> ... cost two per level).  The nodes of the descent are recorded (lane d keeps
+// depth d) for the backpropagation of this selection.
+// cn: the slot's counters, held in registers by the caller (a read-modify-write of a counter in memory is a round trip the
+// wave waits out).  hdr: the root's header when the caller knows it (it just updated the root itself), else null.
+struct NodeHdr { uint32_t meta, first_child; float visits; };
+__device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t slot, uint32_t seg, int lane,
+                                            uint32_t it, float c, uint32_t quirks, uint32_t (&cn)[SC_COUNT], const NodeHdr* hdr) {
     const size_t base = (size_t)slot * T.node_cap;
-    uint32_t* iflag = S.iter_flags + 2 * ((size_t)S.seg[slot] * G.iter_cap + it);    // this batch's flags of iteration `it`
+    uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);            // this batch's flags of iteration `it`
     uint32_t node = 0, depth = 0;
+    uint32_t mine = lane == 0 ? 0u : kNone;
+    uint32_t mt, fc;
+    float nvis;
+    if (hdr) { mt = hdr->meta; fc = hdr->first_child; nvis = hdr->visits; }
+    else { mt = T.meta[base]; fc = T.first_child[base]; nvis = T.visits[base]; }
     for (;;) {
-        const uint32_t k = meta_nch(T.meta[base + node]);
+        const uint32_t k = meta_nch(mt);
         if (k == 0) break;
-        const uint32_t fc = T.first_child[base + node];
-        const float sq = sqrtf(T.visits[base + node]);
+        const float sq = sqrtf(nvis);
         Best b{0.0f, -1};
+        uint32_t bm = 0, bf = 0;                            // header and visits of this lane's best child
+        float bv = 0.0f;
         int lastnan = -1;
         for (uint32_t j = lane; j < k; j += 64) {
             const size_t ci = base + fc + j;
             const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
+            const uint32_t cm = T.meta[ci], cf = T.first_child[ci];
             const float q = vis == 0.0f ? 0.0f : val / vis;
             const float t = sq / (vis + 1.0f);
             const float u = c * t;
             const float w = u * pr;
             const float s = q + w;
             if (s != s) lastnan = (int)j;
-            else if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; }
+            else if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; bm = cm; bf = cf; bv = vis; }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int ln = __shfl_xor(lastnan, d);
-            lastnan = ln > lastnan ? ln : lastnan;
-        }
+        lastnan = wave_allmax_i32(lastnan);
         if (lastnan >= 0) {
             // the sequential fold restarts after a NaN: only children after the last NaN compete
             b.s = 0.0f; b.j = -1;
@@ -104,57 +142,99 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
                 if ((int)j <= lastnan) continue;
                 const size_t ci = base + fc + j;
                 const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
+                const uint32_t cm = T.meta[ci], cf = T.first_child[ci];
                 const float q = vis == 0.0f ? 0.0f : val / vis;
                 const float t = sq / (vis + 1.0f);
                 const float u = c * t;
                 const float w = u * pr;
                 const float s = q + w;
-                if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; }
+                if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; bm = cm; bf = cf; bv = vis; }
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            Best o;
-            o.s = __shfl_xor(b.s, d);
-            o.j = __shfl_xor(b.j, d);
-            b = better(b, o);
-        }
+        b = wave_best(b);
         const int chosen = b.j >= 0 ? b.j : lastnan;       // lastnan == k-1 when nothing follows it
         node = fc + (uint32_t)chosen;
         ++depth;
+        if ((uint32_t)lane == depth) mine = node;
+        if (b.j >= 0) {
+            // the overall best is the best of the lane that scored it (ties go to the later index in both folds)
+            const int owner = __builtin_amdgcn_readfirstlane(chosen & 63);
+            mt = (uint32_t)__builtin_amdgcn_readlane((int)bm, owner);
+            fc = (uint32_t)__builtin_amdgcn_readlane((int)bf, owner);
+            nvis = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), owner));
+        } else {
+            mt = T.meta[base + node]; fc = T.first_child[base + node]; nvis = T.visits[base + node];
+        }
     }
     const BgState st = load_state(&T.state[base + node]);
     const int w = bg_winner_dev(st);
+    const uint32_t plen = depth < (uint32_t)kPathCap ? depth + 1u : 0u;      // 0: deeper than the record holds
+    if (w != 0) {                                           // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
+        const BgState rs = load_state(&T.state[base]);
+        const float v = w == st_player(rs) ? 1.0f : -1.0f;
+        if (plen) backprop_path(T, base, mine, lane, plen, v);
+        else if (lane == 0) backprop(T, base, node, v);
+    } else if ((uint32_t)lane < plen) {
+        S.path[(size_t)slot * kPathCap + lane] = mine;
+    }
+    cn[SC_SELECTIONS] += 1; cn[SC_DEPTH_SUM] += depth;
+    if (w != 0) cn[SC_TERMINAL] += 1;
     if (lane == 0) {
-        uint32_t* sc = S.slot_cnt + slot * SC_COUNT;
-        sc[SC_SELECTIONS] += 1; sc[SC_DEPTH_SUM] += depth;
-        if (w != 0) {                                       // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
-            const BgState rs = load_state(&T.state[base]);
-            const float v = w == st_player(rs) ? 1.0f : -1.0f;
-            backprop(T, base, node, v);
+        if (w != 0) {
             S.leaf_term[slot] = 1;
-            sc[SC_TERMINAL] += 1;
             if (quirks && S.sel[slot] == kNone) atomicAdd(&iflag[1], 1u);
         } else {
             S.leaf_term[slot] = 0; S.leaf[slot] = node; S.sel[slot] = node;
+            S.leaf_meta[slot] = mt; S.path_len[slot] = (uint8_t)plen;
             iflag[0] = 1u;                                  // idempotent plain store (no same-address atomic storm)
             store_state(&S.eval_states[slot], st);
         }
     }
 }
 
+// the slot's counters to and from registers (SC_ILLEGAL is only ever bumped by atomics in memory: it is not written back)
+__device__ __forceinline__ void load_counters(const Slots& S, uint32_t slot, uint32_t (&cn)[SC_COUNT]) {
+    static_assert(SC_COUNT == 8, "two 16-byte loads");
+    const uint4 a = ((const uint4*)(S.slot_cnt + slot * SC_COUNT))[0], b = ((const uint4*)(S.slot_cnt + slot * SC_COUNT))[1];
+    cn[0] = a.x; cn[1] = a.y; cn[2] = a.z; cn[3] = a.w; cn[4] = b.x; cn[5] = b.y; cn[6] = b.z; cn[7] = b.w;
+}
+__device__ __forceinline__ void store_counters(const Slots& S, uint32_t slot, const uint32_t (&cn)[SC_COUNT]) {
+    uint32_t* p = S.slot_cnt + slot * SC_COUNT;
+    ((uint4*)p)[0] = make_uint4(cn[0], cn[1], cn[2], cn[3]);
+    static_assert(SC_ILLEGAL == 6 && SC_NN_ROWS == 7, "word 6 stays in memory");
+    p[4] = cn[4]; p[5] = cn[5]; p[7] = cn[7];
+}
 __global__ __launch_bounds__(64) void k_select(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, float c, uint32_t quirks) {
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
-    select_slot(T, S, G, slot, (int)threadIdx.x, it, c, quirks);
+    uint32_t cn[SC_COUNT];
+    load_counters(S, slot, cn);
+    select_slot(T, S, G, slot, G.n == 1 ? 0u : S.seg[slot], (int)threadIdx.x, it, c, quirks, cn, nullptr);
+    if (threadIdx.x == 0) store_counters(S, slot, cn);
 }
 
 // ---- expansion + backpropagation ---------------------------------------------------------------
+// dev builds (-DDIEE_EXPAND_STAMPS): shader-clock sums per phase of k_expand over all waves, read by scripts/expand_phases.py
+#ifdef DIEE_EXPAND_STAMPS
+__device__ unsigned long long g_expand_stamps[16];
+#define EX_STAMP(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_expand_stamps[i], tn_ - tprev_); tprev_ = __builtin_readcyclecounter(); } while (0)
+#define EX_STAMP_INIT unsigned long long tprev_ = __builtin_readcyclecounter()
+extern "C" int diee_dev_expand_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_expand_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_expand_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define EX_STAMP(i) do {} while (0)
+#define EX_STAMP_INIT do {} while (0)
+#endif
+
 struct ExpandScratch {
     WaveScratch ws;
     float raw[kMaxPlays];
     uint16_t code[kMaxPlays];
 };
+static_assert(sizeof(uint64_t) * 2 * kSeqCap >= sizeof(float) * 22 * 64, "the logits row fits over the dedup keys");
 
 // turn_policy_to_probs_tensor (utils.rs:74-84; root: utils.rs:60-72 on the Dirichlet-mixed policy,
 // noise.rs:27-34) + alpha_expand_tensor (node.rs:157-174).  it == kRootIt expands the roots.
@@ -167,58 +247,93 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     __shared__ ExpandScratch sc;
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
+    EX_STAMP_INIT;
     const int lane = threadIdx.x;
     const size_t base = (size_t)slot * T.node_cap;
     const bool root = it == kRootIt;
     const bool quirks = P.quirks != 0;
+    // Loads in rounds, every round requested as one burst ahead of the integer work: (1) what only depends on the slot,
+    // (2) what depends on the slot's batch and row -- for a single batch that is not compacted, nothing.  (A wave alone on its
+    // SIMD waits out every round trip, and what the previous kernel wrote comes from beyond this XCD's L2: ~1 us each.)
+    const uint32_t seg = G.n == 1 ? 0u : S.seg[slot];
+    const uint32_t rowq = S.slot_row ? S.slot_row[slot] : slot;     // row of this slot in the network outputs (compacted batches
+                                                                    // hold only the slots whose leaf was not terminal)
+    const bool lterm = !root && S.leaf_term[slot] != 0;
+    const uint32_t leaf = root ? 0u : S.leaf[slot];
+    const uint32_t m0q = root ? T.meta[base] : S.leaf_meta[slot];   // the leaf's meta as the selection read it
+    const uint32_t first = T.used[slot];
+    const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
+    uint32_t cn[SC_COUNT];
+    load_counters(S, slot, cn);
+    NodeHdr rh{T.meta[base], T.first_child[base], T.visits[base]};  // the root's header, kept current below for the descent
+    const uint32_t plen = root ? 0u : S.path_len[slot];             // the recorded path of the slot's selection (= sel)
+    const uint32_t pnode = root ? 0u : S.path[(size_t)slot * kPathCap + lane];
+    // the leaf's state: the selection left a copy in eval_states (no leaf -> node -> state chain)
+    const BgState st = load_state(root ? &T.state[base] : &S.eval_states[slot]);
+    const uint32_t row = (lterm && S.slot_row) ? 0u : rowq;         // a slot without a row: its map entry is stale; nothing of row 0 is used
     // the batch ("segment") of this slot: its seed, its flags, and its first slot (the reference's index 0)
-    const uint32_t seg = S.seg[slot];
-    const uint32_t seg_first = G.first_slot[seg];
-    const unsigned long long seed = G.seed[seg];
     const uint32_t* iflag = root ? nullptr : S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
-    const bool active = root || iflag[0] != 0;              // alpha_mcts.rs:170-172 `continue`
+    const uint2 ifl = root ? make_uint2(1u, 0u) : *(const uint2*)iflag;      // any_selected, stale-initial count
+    const uint32_t if0 = ifl.x;
+    const uint32_t seg_first = G.first_slot[seg], seg_end = G.end_slot[seg];
+    const unsigned long long seed = G.seed[seg];
+    const float rv0 = S.root_value0[seg];                           // (written by this batch's first slot at the root iteration)
+    const unsigned long long evals0 = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
+    const uint32_t node = lterm ? 0u : leaf;
+    const uint32_t m0 = lterm ? 0u : m0q;
+    const ValueHeadIn vh = value_head_load(S.hv + (size_t)row * 72, S.wv, lane);
+    float lg[22];
+    softmax_load(S.logits + (size_t)row * 1352, lane, lg);
+    const bool active = if0 != 0;                           // alpha_mcts.rs:170-172 `continue`
+    EX_STAMP(9);                                            // the first round of loads has landed
     if (active) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
-    if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] += G.end_slot[seg] - seg_first;
-    // the row of this slot in the network outputs (a compacted batch holds only the slots whose leaf was not terminal)
-    const uint32_t row = S.slot_row ? S.slot_row[slot] : slot;
-    if (lane == 0 && (root || S.slot_row == nullptr || !S.leaf_term[slot])) S.slot_cnt[slot * SC_COUNT + SC_NN_ROWS] += 1;
+    if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals0 + (seg_end - seg_first);
+    if (root || S.slot_row == nullptr || !lterm) cn[SC_NN_ROWS] += 1;
 
-    uint32_t node = 0;
     float v = 0.0f;
     bool do_expand = true, do_backprop = !root;
     if (!root) {
-        if (S.leaf_term[slot]) {
+        if (lterm) {
             // stale selected_nodes_idxs slot (alpha_mcts.rs:142,192-200): re-"expanded" (no-op) and
             // backpropagated with its own NN value again
             do_expand = false; do_backprop = false;
-            if (quirks && lane == 0) {
+            if (quirks) {
                 const uint32_t s = S.sel[slot];
-                if (s != kNone) backprop(T, base, s, S.sel_value[slot]);
+                if (s != kNone) {
+                    if (plen) backprop_path(T, base, pnode, lane, plen, S.sel_value[slot]);
+                    else if (lane == 0) backprop(T, base, s, S.sel_value[slot]);
+                    rh.visits += 1.0f;                      // the root is on every path
+                }
             }
         } else {
-            node = S.leaf[slot];
-            v = value_head(S.hv + (size_t)row * 72, S.wv, lane);        // the value head's FC + tanh (nn_device.h)
+            v = value_head_eval(vh, lane);                  // the value head's FC + tanh (nn_device.h)
             if (lane == 0) S.sel_value[slot] = v;
         }
     } else if (slot == seg_first) {
-        const float v0 = value_head(S.hv + (size_t)row * 72, S.wv, lane);
+        const float v0 = value_head_eval(vh, lane);
         if (lane == 0) S.root_value0[seg] = v0;
     }
-    const uint32_t m0 = T.meta[base + node];
+    EX_STAMP(0);                                            // flags, value head, leaf meta
     if (do_expand && !(m0 & kDrained)) {
-        const BgState st = load_state(&T.state[base + node]);
         int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
         if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }     // never silent: DIEE_ERR_CAPACITY
+        EX_STAMP(1);                                        // leaf state + legal plays
         const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
-        const float* lrow = S.logits + (size_t)row * 1352;
         float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
-        softmax_consts(lrow, lane, smM, smInv);
+        softmax_reduce(lg, lane, smM, smInv);
+        // this row's logits for the gather by play code: they are in registers already, so no second trip to memory -- staged
+        // over the dedup keys of the play enumeration, which is done with them
+        float* lgs = (float*)&sc.ws.keyA[0];
+#pragma unroll
+        for (int q = 0; q < 22; ++q) lgs[lane + 64 * q] = lg[q];
+        __syncthreads();
+        EX_STAMP(2);                                        // softmax constants
         const float om = 1.0f - P.dir_eps;
         for (int j = lane; j < k; j += 64) {
             const uint32_t play = sc.ws.play[j];
             const uint32_t code = bg_encode_dev(r0, r1, play);
-            float p = softmax_prob(lrow[code], smM, smInv);
+            float p = softmax_prob(lgs[code], smM, smInv);
             if (root) {                                      // apply_dirichlet: (1-eps)*P + eps*noise
                 const float x = om * p, y = P.dir_eps * S.noise[(size_t)seg * 1352 + code];
                 p = x + y;
@@ -238,11 +353,10 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             const int kr = k - 64 * r < 64 ? k - 64 * r : 64;                    // uniform
             for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[r]), j));
         }
-        const uint32_t first = T.used[slot];
+        EX_STAMP(3);                                        // encode + priors + ordered row sum
         if (first + (uint32_t)k > T.node_cap) {
             if (lane == 0) atomicOr(S.overflow, 2u);
         } else {
-            const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
             const uint32_t e = root ? 0u : it + 1u;
             for (int j = lane; j < k; j += 64) {
                 const size_t ci = base + first + j;
@@ -254,32 +368,48 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
                 T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = sc.raw[j] / sum;
                 T.parent[ci] = node; T.first_child[ci] = 0; T.meta[ci] = sc.code[j];
             }
+            const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
             if (lane == 0) {
                 T.first_child[base + node] = first;
-                T.meta[base + node] = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+                T.meta[base + node] = nmeta;
                 T.used[slot] = first + (uint32_t)k;
-                uint32_t* scn = S.slot_cnt + slot * SC_COUNT;
-                scn[SC_EXPANSIONS] += 1; scn[SC_CHILDREN] += (uint32_t)k;
-                if ((uint32_t)k > scn[SC_MAX_CHILDREN]) scn[SC_MAX_CHILDREN] = (uint32_t)k;
             }
+            if (node == 0) { rh.meta = nmeta; rh.first_child = first; }
+            cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
+            if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
         }
     }
+    EX_STAMP(4);                                            // child creation (stores issued)
     __syncthreads();
-    if (lane == 0) {
-        if (do_backprop) backprop(T, base, node, v);
-        if (!root && quirks && slot == seg_first) {
-            // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
-            // i.e. the root in the batch's first slot, with the NN value of its state
-            const uint32_t cnt = iflag[1];
-            const float rv = S.root_value0[seg];
-            for (uint32_t i = 0; i < cnt; ++i) { T.visits[base] += 1.0f; T.value[base] += rv; }
+    EX_STAMP(5);                                            // ... stores acknowledged
+    if (do_backprop) {
+        if (plen) backprop_path(T, base, pnode, lane, plen, v);
+        else if (lane == 0) backprop(T, base, node, v);
+        rh.visits += 1.0f;
+    }
+    if (!root && quirks && slot == seg_first && ifl.y != 0) {
+        // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
+        // i.e. the root in the batch's first slot, with the NN value of its state: the same chain of additions, on registers
+        const uint32_t cnt = ifl.y;
+        for (uint32_t i = 0; i < cnt; ++i) rh.visits += 1.0f;
+        if (lane == 0) {
+            float rvis = T.visits[base], rval = T.value[base];
+            for (uint32_t i = 0; i < cnt; ++i) { rvis += 1.0f; rval += rv0; }
+            T.visits[base] = rvis; T.value[base] = rval;
         }
     }
     }   // active
+    EX_STAMP(6);                                            // backpropagation
     if (next_it != kNoNext) {
         __syncthreads();                                    // lane 0's tree updates are visible to the whole wave
-        select_slot(T, S, G, slot, lane, next_it, c, P.quirks);
+        EX_STAMP(7);
+        select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh);
+        EX_STAMP(8);                                        // descent + leaf state + flags
     }
+    if (lane == 0) store_counters(S, slot, cn);
+#ifdef DIEE_EXPAND_STAMPS
+    if (threadIdx.x == 0) atomicAdd(&g_expand_stamps[15], 1ull);
+#endif
 }
 
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)

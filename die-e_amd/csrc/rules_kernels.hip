@@ -2,6 +2,7 @@
 // One wavefront per state for legal-play enumeration; one lane per state for the scalar functions.
 #include "bg_device.h"
 #include "launch.h"
+#include "wave_ops.h"
 
 namespace diee {
 
@@ -100,6 +101,36 @@ void launch_probe_f32(hipStream_t st, const float* a, const float* b, uint32_t n
 void launch_probe_dice(hipStream_t st, uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni) {
     if (!n) return;
     hipLaunchKernelGGL(k_probe_dice, dim3((n + 255) / 256), dim3(256), 0, st, seed, ctr, n, dice, uni);
+}
+
+// wave_ops.h against the LDS-pipe shuffles it replaces, on lane-dependent data (diee_dev_wave_selftest): mismatching lanes
+__global__ __launch_bounds__(64) void k_wave_selftest(uint32_t* mismatches, uint32_t salt) {
+    const int lane = threadIdx.x;
+    uint32_t bad = 0;
+    for (uint32_t rep = 0; rep < 8; ++rep) {
+        const int v = (int)(((uint32_t)lane * 2654435761u) ^ ((salt + rep) * 0x9E3779B9u) ^ ((uint32_t)lane << (rep + 3)));
+        bad += wave_xor_i32<1>(v) != __shfl_xor(v, 1);   bad += wave_xor_i32<2>(v) != __shfl_xor(v, 2);
+        bad += wave_xor_i32<4>(v) != __shfl_xor(v, 4);   bad += wave_xor_i32<8>(v) != __shfl_xor(v, 8);
+        bad += wave_xor_i32<16>(v) != __shfl_xor(v, 16); bad += wave_xor_i32<32>(v) != __shfl_xor(v, 32);
+        int mx = v;
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+        bad += wave_allmax_i32(v) != mx;
+        const float f = (float)(v >> 8) * 0.37f;
+        float fm = f;
+        for (int d = 32; d >= 1; d >>= 1) fm = fmaxf(fm, __shfl_xor(fm, d));
+        bad += wave_allmax_f32(f) != fm;
+        float fs = f;
+        for (int d = 32; d >= 1; d >>= 1) fs += __shfl_xor(fs, d);
+        bad += __builtin_bit_cast(uint32_t, wave_butterfly_sum(f)) != __builtin_bit_cast(uint32_t, fs);
+        const int x = (v >> 20) & 31;
+        int incl = x;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        bad += wave_inclusive_scan_i32(x) != incl;
+    }
+    atomicAdd(mismatches, bad);
+}
+void launch_wave_selftest(hipStream_t st, uint32_t* mismatches, uint32_t salt) {
+    hipLaunchKernelGGL(k_wave_selftest, dim3(4), dim3(64), 0, st, mismatches, salt);
 }
 
 }  // namespace diee

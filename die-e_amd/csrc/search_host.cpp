@@ -27,7 +27,8 @@ struct SearchBufs {
     DevBuf<BgState> roots, eval_states;
     DevBuf<uint32_t> game_id, round, seg, leaf, sel, iter_flags, row_slot, slot_row, n_rows;
     DevBuf<float> sel_value, noise, root_value0;
-    DevBuf<uint8_t> leaf_term;
+    DevBuf<uint8_t> leaf_term, path_len;
+    DevBuf<uint32_t> path, leaf_meta;
     DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
@@ -114,6 +115,7 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.used.ensure(sc);
         B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc); B.seg.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
+        B.path.ensure((size_t)sc * kPathCap); B.path_len.ensure(sc); B.leaf_meta.ensure(sc);
         B.row_slot.ensure(sc); B.slot_row.ensure(sc); B.n_rows.ensure(4);
         B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
@@ -135,7 +137,8 @@ Tree tree_view(SearchBufs& B) {
 Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
-                 nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p};
+                 nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p,
+                 B.leaf_meta.p, B.path.p, B.path_len.p};
 }
 Segs segs_view(SearchBufs& B, uint32_t n_segs) {
     return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};

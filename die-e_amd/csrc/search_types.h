@@ -69,7 +69,11 @@ struct Slots {
     uint32_t* slot_cnt;     // [slots][SC_COUNT] per-slot counters of this move-step: same-address atomics from a
                             // thousand waves serialise at ~11 ns each, per-slot words cost nothing
     uint32_t* overflow;     // capacity flag (bit0 sequence table, bit1 tree arena)
+    uint32_t* leaf_meta;    // [slots] Tree::meta of leaf as the selection read it (nobody else writes this game's tree)
+    uint32_t* path;         // [slots][kPathCap] nodes from the root to sel (entry d = depth d): backpropagation without the parent walk
+    uint8_t* path_len;      // [slots] entries of path; 0 = deeper than kPathCap (or no selection yet): walk the parents
 };
+constexpr int kPathCap = 64;
 
 struct Games {
     BgState* state;         // [games]

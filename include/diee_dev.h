@@ -28,6 +28,10 @@ diee_status diee_dev_conv_bench(diee_ctx*, int G, int variant, int reps, float* 
 diee_status diee_dev_rules_bench(diee_ctx*, const diee_bg_state* states, uint32_t n, int reps,
                                  float* us_legal_moves, float* mean_plays);
 
+/* the DPP / permlane forms of the wave-wide operations (csrc/wave_ops.h) against the __shfl forms they replace, on
+ * lane-dependent data: the number of lanes x cases that disagree (0 on a correct build) */
+diee_status diee_dev_wave_selftest(diee_ctx*, uint32_t salt, uint32_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

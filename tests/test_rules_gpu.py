@@ -141,3 +141,10 @@ def test_rules_bench_probe_counts_the_same_plays(eng, oracle, states):
     us, mean_plays = eng.rules_bench(sub, reps=3)
     assert us > 0.0
     assert abs(mean_plays - float(ref_counts.mean())) < 1e-3
+
+
+def test_wave_ops_agree_with_the_shuffles_they_replace(eng):
+    """csrc/wave_ops.h (DPP / v_permlane*_swap forms of xor exchange, all-max, butterfly sum, prefix scan) against
+    __shfl_xor / __shfl_up on lane-dependent data: bit-identical on every lane, for several data patterns"""
+    for salt in (0, 1, 12345, 0xDEADBEEF):
+        assert eng.wave_selftest(salt) == 0
