@@ -168,7 +168,7 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
     }
     const BgState st = load_state(&T.state[base + node]);
     const int w = bg_winner_dev(st);
-    const uint32_t plen = depth < (uint32_t)kPathCap ? depth + 1u : 0u;      // 0: deeper than the record holds
+    const uint32_t plen = depth < S.path_cap ? depth + 1u : 0u;              // 0: deeper than the record holds
     if (w != 0) {                                           // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
         const BgState rs = load_state(&T.state[base]);
         const float v = w == st_player(rs) ? 1.0f : -1.0f;

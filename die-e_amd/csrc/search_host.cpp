@@ -138,7 +138,7 @@ Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
                  nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p,
-                 B.leaf_meta.p, B.path.p, B.path_len.p};
+                 B.leaf_meta.p, B.path.p, B.path_len.p, std::min<uint32_t>(env_u32("DIEE_PATH_CAP", kPathCap), kPathCap)};
 }
 Segs segs_view(SearchBufs& B, uint32_t n_segs) {
     return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};

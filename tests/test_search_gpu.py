@@ -244,3 +244,30 @@ def test_compacted_evaluation_changes_nothing_but_the_row_count(oracle, monkeypa
     assert b["stats"]["nn_rows"] == b["stats"]["nn_evals"] == 13 * n
     assert a["stats"]["terminal_hits"] > 0
     assert a["stats"]["nn_rows"] == a["stats"]["nn_evals"] - a["stats"]["terminal_hits"]      # one row saved per terminal selection
+
+
+@pytest.mark.parametrize("cap", ["1", "2", "3"])
+def test_parent_walk_backpropagation_equals_the_recorded_path(oracle, monkeypatch, cap):
+    """k_expand backpropagates over the root-to-leaf path its selection recorded (one lane per level); selections deeper
+    than the record fall back to walking the parent indices.  DIEE_PATH_CAP lowers the record so that ordinary searches
+    reach the fallback in the stale-slot re-backpropagation (Q14), the terminal-leaf backpropagation of the descent and the
+    ordinary one: results and counters identical to the default"""
+    import diee_amd
+    walk = oracle.random_walk_states(91, 60)
+    late = walk[walk["off"].max(axis=1) >= 11][:24]
+    states = np.concatenate([late, walk[150:150 + 5 * 40:5]])
+    n = len(states)
+    _, gcfg = cfgs(oracle, 48)
+    gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 7
+    res = []
+    for c in (None, cap):
+        if c is None: monkeypatch.delenv("DIEE_PATH_CAP", raising=False)
+        else: monkeypatch.setenv("DIEE_PATH_CAP", c)
+        e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+        res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 5, gids, rds, ref_quirks=True))
+        e.close()
+    a, b = res
+    assert a["probs"].tobytes() == b["probs"].tobytes() and (a["root_visits"] == b["root_visits"]).all()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert a["stats"][key] == b["stats"][key], key
+    assert a["stats"]["terminal_hits"] > 0 and a["stats"]["depth_sum"] > 2 * a["stats"]["selections"]     # deeper than every cap tried
