@@ -5,6 +5,7 @@
 #include "nn_host.h"
 #include "launch.h"
 
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -220,6 +221,8 @@ diee_status diee_dev_wave_selftest(diee_ctx* c, uint32_t salt, uint32_t* mismatc
 // ---- training-step kernels: stateless, on the caller's stream ----
 static const float* zero_bias256() {
     static float* z[16] = {nullptr};                             // one 1 KB allocation per device the process trains on
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!z[dev]) {

@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "launch.h"
 
 namespace diee {
@@ -457,6 +459,8 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_coop(const uint16_t* __restrict
 static uint32_t* bn_sync_words(int& resident) {
     static uint32_t* w[16] = {nullptr};
     static int res[16] = {0};
+    static std::mutex mu;                               // two host threads may take their first training step together
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     resident = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256) void k_wgrad_fold(const float* __restrict__ pa
 
 size_t wgrad_scratch_floats() { return (size_t)kWgSplit * 9 * 256 * 256; }
 void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards) {
-    static bool attr_set = false;
+    static bool attr_set = false;                       // (idempotent: a race sets the same attribute twice)
     constexpr int lds = kWgXBytes + kWgYBytes;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
     hipLaunchKernelGGL(k_wgrad3x3, dim3(16, kWgSplit), dim3(512), lds, st, x, dy, partial, boards * 24);
