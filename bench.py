@@ -234,6 +234,7 @@ def main():
 
     keys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
+            "full_seconds", "full_launches", "full_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
             "fragments", "illegal_decodes"]
     if dist is not None:
@@ -273,7 +274,14 @@ def main():
         # the tower of 38 3x3 convs is ~90 % of the GPU time; it runs as ONE fused launch (k_tower16: activations in LDS)
         # while more than 256 games are alive and as ONE cluster launch (k_tower_cl: 8-workgroup clusters per board group)
         # at 256 games or fewer; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
-        r_fused = roof("k_tower16 (38 fused 3x3 conv layers in one launch, v_mfma_f32_16x16x32_bf16; batches > 256 boards)",
+        # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch (33 % of the batch's
+        # kernel time; 58 % of the default run's with the pipelined leg).  Its sampled launches are timed one to one, so
+        # `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
+        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r02g_bench_headline_kernel_stats.csv).  `roofline_other` keeps
+        # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
+        r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
+                      tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"))
+        r_fused = roof("k_tower16, every geometry (<4,8,3>, <4,8,6>, <2,8,9>): all evaluations of batches > 256 boards, timed per evaluation (a compacted evaluation is up to three launches)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],
@@ -281,7 +289,10 @@ def main():
         r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; only when the other two are disabled)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
-        dominant, other = ranked[0], ranked[1:]
+        if r_full:                                   # a single kernel, comparable with its row in a rocprofv3 summary
+            dominant, other = r_full, ranked
+        else:                                        # batches that never fill the chip (--games <= 928)
+            dominant, other = ranked[0], ranked[1:]
         out = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,

@@ -76,7 +76,8 @@ class Stats(C.Structure):
                    ("conv_launches", C.c_uint64), ("conv_flops", C.c_double),
                    ("tower_seconds", C.c_double), ("tower_launches", C.c_uint64), ("tower_flops", C.c_double),
                    ("cluster_seconds", C.c_double), ("cluster_launches", C.c_uint64), ("cluster_flops", C.c_double),
-                   ("nn_rows", C.c_uint64)])
+                   ("nn_rows", C.c_uint64),
+                   ("full_seconds", C.c_double), ("full_launches", C.c_uint64), ("full_flops", C.c_double)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

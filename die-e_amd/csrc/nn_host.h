@@ -47,7 +47,7 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower, 2 cluster
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower, 3 fused tower as one <4,8,3> launch, 2 cluster
                                     // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
     bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
     int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)
@@ -58,6 +58,8 @@ struct NetWeights {
     uint64_t forward_count = 0;
     double conv_seconds = 0, conv_flops = 0, tower_seconds = 0, tower_flops = 0, cluster_seconds = 0, cluster_flops = 0;
     uint64_t conv_launches = 0, tower_launches = 0, cluster_launches = 0;
+    double full_seconds = 0, full_flops = 0;      // the subset of the fused-tower samples that were ONE k_tower16<4,8,3> launch
+    uint64_t full_launches = 0;
     hipEvent_t get_event() {
         if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
         hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;

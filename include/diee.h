@@ -101,6 +101,9 @@ typedef struct {
     double   cluster_flops;
     uint64_t nn_rows;          /* rows the ResNet really evaluated: above 256 live games the rows of slots whose selected leaf
                                   was terminal (stale in the reference, never read) are skipped; nn_evals keeps the reference's count */
+    double   full_seconds;     /* the subset of the tower_* samples that were exactly ONE k_tower16<4,8,3> launch (929 ... 1024   */
+    uint64_t full_launches;    /* boards, or whole multiples of 1024): comparable one to one with that kernel's row in a          */
+    double   full_flops;       /* rocprofv3 --kernel-trace --stats summary                                                        */
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */
