@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of the default bench command for profiles/ (run on the GPU box from the repo root):
-#   scripts/profile_bench.sh TAG    ->  gpurun_out/TAG_kernel_stats.csv, TAG_line.json, TAG_pmc_traffic*.json
+#   scripts/profile_bench.sh TAG    ->  gpurun_out/TAG_kernel_stats.csv, TAG_line.json, TAG_headline_kernel_stats.csv, TAG_headline_line.json, TAG_pmc_traffic*.json
 # Pass 1: rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu-baseline` (whole run: headline batch + pipelined).
 # Pass 2/3: --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) of the first move-step at 1024 and 32 boards.
 set -u
@@ -12,6 +12,9 @@ cd /tmp && export TMPDIR=/tmp
 W=/tmp/prof_$TAG; rm -rf "$W"; mkdir -p "$W"
 rocprofv3 --kernel-trace --stats -d "$W/full" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/${TAG}_line.json" 2> "$OUT/${TAG}_err.log"
 cp "$(find "$W/full" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+# Pass 1b: the timed leg alone (one batch at a time): k_tower16<4,8,3>'s AverageNs here is what roofline.avg_launch_us must agree with
+rocprofv3 --kernel-trace --stats -d "$W/headline" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --pipeline 0 > "$OUT/${TAG}_headline_line.json" 2>> "$OUT/${TAG}_err.log"
+cp "$(find "$W/headline" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_headline_kernel_stats.csv"
 for G in 1024 32; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C -d "$W/pmc_${C}_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --games $G > /dev/null 2>> "$OUT/${TAG}_err.log"
