@@ -114,25 +114,33 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
     float nvis;
     if (hdr) { mt = hdr->meta; fc = hdr->first_child; nvis = hdr->visits; }
     else { mt = T.meta[base]; fc = T.first_child[base]; nvis = T.visits[base]; }
+    BgState cur;                                            // state of `node` when the level above carried it along
+    bool cur_ok = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cur.w[q] = 0u;
     for (;;) {
         const uint32_t k = meta_nch(mt);
         if (k == 0) break;
         const float sq = sqrtf(nvis);
         Best b{0.0f, -1};
-        uint32_t bm = 0, bf = 0;                            // header and visits of this lane's best child
+        uint32_t bm = 0, bf = 0;                            // header, visits and state of this lane's best child
         float bv = 0.0f;
+        BgState bs;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bs.w[q] = 0u;
         int lastnan = -1;
         for (uint32_t j = lane; j < k; j += 64) {
             const size_t ci = base + fc + j;
             const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
             const uint32_t cm = T.meta[ci], cf = T.first_child[ci];
+            const BgState cs = load_state(&T.state[ci]);    // rides the same round trip: the leaf's state needs none of its own
             const float q = vis == 0.0f ? 0.0f : val / vis;
             const float t = sq / (vis + 1.0f);
             const float u = c * t;
             const float w = u * pr;
             const float s = q + w;
             if (s != s) lastnan = (int)j;
-            else if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; bm = cm; bf = cf; bv = vis; }
+            else if (b.j < 0 || !(b.s > s)) { b.s = s; b.j = (int)j; bm = cm; bf = cf; bv = vis; bs = cs; }
         }
         lastnan = wave_allmax_i32(lastnan);
         if (lastnan >= 0) {
@@ -156,17 +164,21 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
         node = fc + (uint32_t)chosen;
         ++depth;
         if ((uint32_t)lane == depth) mine = node;
-        if (b.j >= 0) {
+        if (b.j >= 0 && lastnan < 0) {
             // the overall best is the best of the lane that scored it (ties go to the later index in both folds)
             const int owner = __builtin_amdgcn_readfirstlane(chosen & 63);
             mt = (uint32_t)__builtin_amdgcn_readlane((int)bm, owner);
             fc = (uint32_t)__builtin_amdgcn_readlane((int)bf, owner);
             nvis = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), owner));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)bs.w[q], owner);
+            cur_ok = true;
         } else {
             mt = T.meta[base + node]; fc = T.first_child[base + node]; nvis = T.visits[base + node];
+            cur_ok = false;
         }
     }
-    const BgState st = load_state(&T.state[base + node]);
+    const BgState st = cur_ok ? cur : load_state(&T.state[base + node]);
     const int w = bg_winner_dev(st);
     const uint32_t plen = depth < S.path_cap ? depth + 1u : 0u;              // 0: deeper than the record holds
     if (w != 0) {                                           // alpha_mcts.rs:157-163: +-1 w.r.t. the ROOT player
