@@ -404,8 +404,17 @@ __device__ __forceinline__ u32x4 ld_coherent16(__amdgpu_buffer_rsrc_t r, int byt
     const rb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
     return u32x4{v[0], v[1], v[2], v[3]};
 }
+// Producer stores are PLAIN: a cluster lives on one XCD (see the blockIdx -> (xcd, slice, group) mapping in k_tower_cl), the
+// vector L1 is write-through, so a plain store lands in that XCD's L2 and STAYS there, where the consumers' sc1 (L1-bypassing,
+// L2-served) loads find it; an sc1 store also writes through to memory and drops the line, and the same-XCD reader then pays the
+// cross-XCD rate (guide: 104-122 vs 66-73 GB/s per block, +0.1-0.3 us per hand-off).  Measured: cluster forward 122.2 ->
+// 119.3 us at 8 boards, 350 -> 340 us at 256, +0.6 % games/s (same box).  A cluster that did NOT sit on one XCD would never
+// see the data: its polls time out and the engine falls back (loud), it cannot read a half-written tile (tags per 8 bytes).
+#ifndef DIEE_CL_STORE_AUX
+#define DIEE_CL_STORE_AUX 0       // 16 = sc1 (write-through past the XCD's L2, round 1); 0 = plain (the line stays in the XCD's L2)
+#endif
 __device__ __forceinline__ void st_coherent16(__amdgpu_buffer_rsrc_t r, int byte_off, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, r, byte_off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, r, byte_off, 0, DIEE_CL_STORE_AUX);
 }
 
 // Ready flag carried by the data: activations are post-ReLU bf16, so their sign bits are free.  The output of layer w
