@@ -879,6 +879,11 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
                                               const float* __restrict__ bias, const uint32_t (&basep)[9][((GT * 24 + 15) / 16 + 1) / 2],
                                               u32x4 (&bq)[PF][16 / NW], int lane, int wave) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 15) / 16, NFR = 16 / NW;
+#ifdef DIEE_TOWER_HALFN
+    constexpr int NQ = NW == 4 ? NFR / 2 : NFR;       // timing experiment: half the output channels per workgroup (wrong results)
+#else
+    constexpr int NQ = NFR;
+#endif
     f32x4 acc[MF][NFR];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
@@ -910,7 +915,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
                 const int sp = it * 18 + u + PF;               // k-step to prefetch (of the next layer past 72)
                 const u32x4* src = sp < 72 ? wp + (size_t)sp * 64 : wp_next + (size_t)(sp - 72) * 64;
 #pragma unroll
-                for (int q = 0; q < NFR; ++q) bq[u % PF][q] = src[(size_t)q * 72 * 64];
+                for (int q = 0; q < NQ; ++q) bq[u % PF][q] = src[(size_t)q * 72 * 64];
             }
 #if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
@@ -919,7 +924,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             for (int f = 0; f < MF; ++f) {
                 if (border_skip(SP, u % 9, f)) continue;           // this fragment x tap is all padding
 #pragma unroll
-                for (int q = 0; q < NFR; ++q)
+                for (int q = 0; q < NQ; ++q)
                     acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);   // D = W^T x act^T
             }
 #if DIEE_TOWER_SCHED == 0
