@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r03a_mfma_busy.json", "r03a_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh
 
 
 def host_cores():
@@ -52,6 +53,51 @@ def host_cores():
     return n
 
 
+# ---- B-omp workers: one PROCESS per host core (forked before anything starts a thread pool), each with its own
+# single-threaded fp32 PyTorch ResNet and its own oracle trees: no GIL between the searches (round 2 ran them as threads of
+# one interpreter and measured the interpreter lock: 222 expansions/s on 16 threads, slower than the serial B-ref)
+_W = {}
+
+
+def _omp_init(seed):
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    import diee_amd
+    from oracle import oracle as orc
+    from oracle import nn_ref
+    orc.build()
+    net = nn_ref.parse(diee_amd.random_weights(0))
+
+    def fn(states_u8):
+        st = states_u8.view(orc.BG_STATE).reshape(-1)
+        pol, val, _ = nn_ref.forward_t(net, orc.planes_batch(st))
+        return pol, val
+    _W.update(orc=orc, fn=fn, np=np, seed=seed)
+
+
+def _omp_calibrate(root_bytes):
+    np = _W["np"]
+    st = np.frombuffer(root_bytes, dtype=np.uint8).reshape(-1, 32)
+    _W["fn"](st)
+    t = time.time(); _W["fn"](st); _W["fn"](st)
+    return (time.time() - t) / 2
+
+
+def _omp_search(job):
+    root_bytes, first_id, iters = job
+    orc, np = _W["orc"], _W["np"]
+    states = np.frombuffer(root_bytes, dtype=orc.BG_STATE)
+    out = []
+    for i in range(len(states)):                       # one root after the other: batch-1 evaluations, as rayon over games would
+        cfg = orc.MctsCfg(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+        ev = orc.make_eval(_W["fn"], 1352)
+        _, _, st, _ = orc.alpha_mcts_parallel(1, states[i:i + 1], cfg, ev, None, _W["seed"], 0, np.arange(first_id + i, first_id + i + 1, dtype=np.uint32),
+                                              np.zeros(1, dtype=np.uint32), 1)
+        out.append(st.as_dict())
+    return out
+
+
 def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
@@ -60,21 +106,47 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
 
       B-ref  as die-e runs self-play today: ONE batched search over all roots, tree loops on one thread
              (alpha_mcts.rs:153-168,192-200), the network batch on every core (libtorch intra-op pool);
-      B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308): one search per root,
-             one root per host thread, batch-1 network evaluations on that thread -- no cross-game batching, no
-             serial section.
+      B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308, pool sized at main.rs:107-110):
+             one search per root, one PROCESS per host core (the reference's rayon threads share no interpreter lock; Python
+             threads would), batch-1 single-threaded network evaluations -- no cross-game batching, no serial section.
     Returns the faster of the two as `value` (games/s, extrapolated with the GPU run's expansions per game)."""
-    import concurrent.futures as cf
-    import numpy as np
-    import torch
-    import diee_amd
-    from oracle import oracle as orc
-    from oracle import nn_ref
-    orc.build()
-    net = nn_ref.parse(diee_amd.random_weights(0))
+    import multiprocessing as mp
     cores = host_cores()
+    workers = max(1, min(cores, n_roots))
+    # fork the B-omp workers FIRST: this process has not imported torch yet, so no OpenMP / intra-op pool exists to be
+    # broken by the fork; every worker builds its own network
+    pool = mp.get_context("fork").Pool(workers, initializer=_omp_init, initargs=(seed,))
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
     walk = orc.random_walk_states(seed & 0xFFFF, 40)
     roots = walk[np.linspace(3, len(walk) - 1, n_roots).astype(int)]
+    out = {"unit": "games/s", "kind": "port", "cores": cores, "host_threads_visible": os.cpu_count(), "variants": {}}
+    # ---- B-omp ----
+    try:
+        t_eval = max(pool.map(_omp_calibrate, [roots[i:i + 1].tobytes() for i in range(workers)]))     # per-evaluation time with every worker busy
+        shares = [roots[i::workers] for i in range(workers)]
+        per_worker = max(len(sh) for sh in shares)
+        it_omp = int(max(2, min(iterations, budget_s / (t_eval * per_worker) - 1)))
+        t = time.time()
+        res = pool.map(_omp_search, [(sh.tobytes(), 1000 * i, it_omp) for i, sh in enumerate(shares)])
+        dt = time.time() - t
+        sts = [s for r in res for s in r]
+        exps = sum(s["expansions"] for s in sts)
+        out["variants"]["B-omp"] = {
+            "expansions_per_s": exps / dt, "seconds": dt, "threads": workers, "iterations_of_the_sample": it_omp,
+            "batch1_eval_ms": t_eval * 1e3,
+            "mean_children": sum(s["children"] for s in sts) / max(exps, 1),
+            "mean_leaf_depth": sum(s["depth_sum"] for s in sts) / max(sum(s["selections"] for s in sts), 1),
+            "what": f"{n_roots} independent searches over {workers} worker PROCESSES (one per host core, forked before any thread pool), "
+                    "oracle tree in C + batch-1 single-threaded fp32 PyTorch evaluations in each"}
+    finally:
+        pool.close(); pool.join()
+    # ---- B-ref ----
+    import torch
+    import diee_amd
+    from oracle import nn_ref
+    net = nn_ref.parse(diee_amd.random_weights(0))
 
     def fn(states_u8):
         st = states_u8.view(orc.BG_STATE).reshape(-1)
@@ -93,8 +165,6 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
         fn(states.view(np.uint8).reshape(-1, 32))                           # warm-up (primitive creation)
         t = time.time(); fn(states.view(np.uint8).reshape(-1, 32)); return max(time.time() - t, 1e-4)
 
-    out = {"unit": "games/s", "kind": "port", "cores": cores, "host_threads_visible": os.cpu_count(), "variants": {}}
-    # B-ref
     torch.set_num_threads(cores)
     it_ref = int(max(2, min(iterations, budget_s / calibrate(roots) - 1)))
     t = time.time(); st = search(roots, 0, it_ref); dt = time.time() - t
@@ -102,24 +172,6 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
         "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores, "iterations_of_the_sample": it_ref,
         "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
         "what": f"one batched search over {n_roots} roots (serial C tree loops + fp32 PyTorch CPU ResNet on {cores} intra-op threads)"}
-    # B-omp
-    torch.set_num_threads(1)
-    workers = max(1, min(cores, n_roots))
-    per_thread = -(-n_roots // workers)                                     # roots a thread searches one after the other
-    with cf.ThreadPoolExecutor(workers) as ex:
-        t = time.time(); list(ex.map(lambda i: calibrate(roots[i:i + 1]), range(workers)))      # per-evaluation time with every thread busy
-        t_eval = (time.time() - t) / 2
-        it_omp = int(max(2, min(iterations, budget_s / (t_eval * per_thread) - 1)))
-        t = time.time()
-        sts = list(ex.map(lambda i: search(roots[i:i + 1], i, it_omp), range(n_roots)))
-        dt = time.time() - t
-    exps = sum(s["expansions"] for s in sts)
-    out["variants"]["B-omp"] = {
-        "expansions_per_s": exps / dt, "seconds": dt, "threads": workers, "iterations_of_the_sample": it_omp,
-        "mean_children": sum(s["children"] for s in sts) / max(exps, 1),
-        "mean_leaf_depth": sum(s["depth_sum"] for s in sts) / max(sum(s["selections"] for s in sts), 1),
-        "what": f"{n_roots} independent searches, one per host thread ({workers} threads), batch-1 fp32 evaluations on that thread"}
-    torch.set_num_threads(cores)
     best = max(out["variants"], key=lambda k: out["variants"][k]["expansions_per_s"])
     eps = out["variants"][best]["expansions_per_s"]
     out["expansions_per_s"] = eps
@@ -150,7 +202,9 @@ def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=240):
     return {"value": None, "unit": "games/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {why}"}
 
 
-def main():
+def main(argv=None, engine_factory=None):
+    """argv / engine_factory: tests/test_dist_cpu.py drives this very function on two gloo ranks with a stand-in engine
+    (DIEE_BENCH_BACKEND=gloo: CPU tensors for the reductions, no torch.cuda call); the driver and users run it as a script."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
@@ -164,7 +218,7 @@ def main():
     ap.add_argument("--exp-per-game", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--pipeline", type=int, default=4, help="also time K batches played side by side through diee_self_play_multi "
                     "(self_play_iterations of the learn loop; 0 = skip); reported as value_pipelined, never as value")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.cpu_baseline_only:                   # child of cpu_baseline_guarded: CPU only, never touches the GPU
         print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game)))
         return
@@ -172,23 +226,26 @@ def main():
     import importlib
     ddist = importlib.import_module("die-e_amd.dist")
     rank, local_rank, world = ddist.rank_world()
+    backend = os.environ.get("DIEE_BENCH_BACKEND", "nccl")      # "gloo": the CPU test of this function
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     dev = local_rank
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
-        # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
-        ndev = max(torch.cuda.device_count(), 1)
-        dev = local_rank % ndev
-        if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
-            # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
-            # which two processes on one GPU cannot promise each other
-            os.environ["DIEE_TOWER_CL"] = "none"
-        torch.cuda.set_device(dev)                 # torch's HIP runtime initialises before libdiee.so's
-        dist.init_process_group("nccl")            # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
+            ndev = max(torch.cuda.device_count(), 1)
+            dev = local_rank % ndev
+            if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+                # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
+                # which two processes on one GPU cannot promise each other
+                os.environ["DIEE_TOWER_CL"] = "none"
+            torch.cuda.set_device(dev)             # torch's HIP runtime initialises before libdiee.so's
+        dist.init_process_group(backend)           # "nccl" is RCCL on ROCm
 
     import diee_amd
-    eng = diee_amd.Engine(dev)                     # raises without a GPU: there is no CPU path
+    eng = (engine_factory or diee_amd.Engine)(dev)   # raises without a GPU: there is no CPU path
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     first_id = ddist.shard_first_game_id(rank, args.games)
@@ -197,9 +254,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
 
     def run_step(i):
         return eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
@@ -237,12 +295,16 @@ def main():
             "full_seconds", "full_launches", "full_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
             "fragments", "illegal_decodes"]
+    frags_per_rank = [int(tot.get("fragments", 0))]
     if dist is not None:
-        dt, red = ddist.reduce_stats(dist, dt, tot, keys, "cuda")
+        # after a self-play batch the ranks all-gather their fragment counts (8 x u64 on a node) -- what a
+        # consumer of the sharded records (the learn loop's trainer) needs to size its receive buffers; the records stay put
+        frags_per_rank = ddist.gather_counts(dist, frags_per_rank[0], red_dev)
+        dt, red = ddist.reduce_stats(dist, dt, tot, keys, red_dev)
         tot.update(red)
         if pipe is not None:
             pkeys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "fragments", "tower_seconds", "tower_launches", "tower_flops"]
-            dtp, red = ddist.reduce_stats(dist, dtp, pipe, pkeys, "cuda")
+            dtp, red = ddist.reduce_stats(dist, dtp, pipe, pkeys, red_dev)
             pipe.update(red)
 
     if rank == 0:
@@ -260,13 +322,29 @@ def main():
             except Exception:
                 return None
 
-        def roof(kernel, sec, launches, flops, traffic=None):
+        def pmc_mfma(name, fname):
+            # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE of `bench.py --max-steps 1 --pipeline 0 [--games 32]`
+            # (scripts/pmc_mfma.sh): share of the chip's SIMD-cycles with a matrix instruction executing, and the clock held
+            try:
+                doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                for k, v in doc["kernels"].items():
+                    if k.startswith(name) and "mfma_busy_frac" in v:
+                        return {"mfma_busy_frac": v["mfma_busy_frac"], "clock_mhz": v["clock_mhz"], "us": v["duration_us"]}
+            except Exception:
+                pass
+            return None
+
+        def roof(kernel, sec, launches, flops, traffic=None, busy=None, busy_file=None):
             if not sec:
                 return None
             a = flops / sec / 1e12
             return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": a / PEAK_BF16_TFLOPS, "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/ (separate rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
+                    "mfma_busy_frac": None if busy is None else busy["mfma_busy_frac"],
+                    "mfma_busy_clock_mhz": None if busy is None else busy["clock_mhz"],
+                    "mfma_busy_source": None if busy is None else f"profiles/{busy_file} (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                                                                   "of this command's first move-step, committed; busy cycles / (256 CUs x 4 SIMDs x GRBM_GUI_ACTIVE / 8); not re-measured in this run)",
                     "launches_sampled": launches / world,
                     "avg_launch_us": sec / max(launches, 1) * 1e6,
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
@@ -280,19 +358,23 @@ def main():
         # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r02g_bench_headline_kernel_stats.csv).  `roofline_other` keeps
         # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
         r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
-                      tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"))
+                      tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"),
+                      pmc_mfma("diee::k_tower16<4", MFMA_BUSY_FILE), MFMA_BUSY_FILE)
         r_fused = roof("k_tower16, every geometry (<4,8,3>, <4,8,6>, <2,8,9>): all evaluations of batches > 256 boards, timed per evaluation (a compacted evaluation is up to three launches)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_cluster = roof("k_tower_cl (38 tower layers in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],
-                         pmc_traffic("diee::k_tower_cl<1", "r02_pmc_traffic_32boards.json"))
+                         pmc_traffic("diee::k_tower_cl<1", "r02_pmc_traffic_32boards.json"),
+                         pmc_mfma("diee::k_tower_cl<1", MFMA_BUSY_FILE_32), MFMA_BUSY_FILE_32)
         r_layer = roof("k_conv3x3_sk (per-layer 3x3 tower conv, split-K; only when the other two are disabled)",
                        tot["conv_seconds"], tot["conv_launches"], tot["conv_flops"])
         ranked = sorted([r for r in (r_fused, r_cluster, r_layer) if r], key=lambda r: -r["share_of_sampled_tower_time"])
         if r_full:                                   # a single kernel, comparable with its row in a rocprofv3 summary
             dominant, other = r_full, ranked
-        else:                                        # batches that never fill the chip (--games <= 928)
+        elif ranked:                                 # batches that never fill the chip (--games <= 928)
             dominant, other = ranked[0], ranked[1:]
+        else:                                        # nothing was sampled (a run too short for a sample)
+            dominant, other = None, []
         out = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -311,7 +393,10 @@ def main():
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
                       "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"]},
             "roofline": dominant, "roofline_other": other,
+            "fragments_per_rank": frags_per_rank,    # all_gather of the per-rank record counts; the records stay on their rank
         }
+        out["scale_note"] = ("N>1 never run on hardware by the build (gpurun boxes have one GPU); ranks are independent workers (no data-path collective): expected weak scaling = N x the 1-GPU value; "
+                                 "this code path has run under torch.distributed.run at world size 1 on RCCL (tests/test_dist_gpu.py) and at world size 2 on gloo (tests/test_dist_cpu.py)")
         if pipe is not None:
             # NOT the headline: `value` above stays one self_play_parallel call per step, as the reference issues them
             out["value_pipelined"] = pipe["games"] / dtp

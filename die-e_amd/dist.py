@@ -23,3 +23,13 @@ def reduce_stats(dist, elapsed, totals, keys, device):
     v = torch.tensor([float(totals.get(k, 0)) for k in keys], dtype=torch.float64, device=device)
     dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return float(t.item()), {k: float(x) for k, x in zip(keys, v.tolist())}
+
+
+def gather_counts(dist, count, device):
+    """all_gather of one per-rank u64 (the fragment counts of a self-play batch, 8 x u64 on a node): what a
+    consumer of the sharded records needs to size its buffers; the records themselves stay on their rank"""
+    import torch
+    mine = torch.tensor([int(count)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [int(t.item()) for t in out]

@@ -109,3 +109,89 @@ def test_two_rank_ddp_training_step_gloo():
     assert len(l0) == len(l1) == 2     # min(ceil(8/4), ceil(14/4)) all-reduced steps on both ranks: nobody waits forever
     assert l0 != l1                    # different shards, different losses
     assert a0 == a1 and b0 == b1       # identical blobs (parameters AND BatchNorm statistics) after sync_engine
+
+
+# ---- bench.py's own main() on two gloo ranks ---------------------------------------------------------------------------
+class _StubEngine:
+    """stand-in for diee_amd.Engine in the CPU test of bench.main(): plays the rank's shard with the CPU oracle (hash
+    evaluator) and returns the engine's stats dictionary; the sampled tower timings stay zero (no network kernels ran)"""
+
+    def __init__(self, device):
+        self.device = device
+
+    def load_weights(self, blob):
+        assert len(blob) > 1000
+
+    @staticmethod
+    def _stats(out, n):
+        import importlib
+        pkg = importlib.import_module("die-e_amd")
+        st = {name: 0 for name, _ in pkg.Stats._fields_}
+        for k in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "illegal_decodes", "max_children"):
+            st[k] = out["stats"][k]
+        st.update(games=n, plies=int(out["plies"].sum()), move_steps=out["steps"], fragments=len(out["outcome"]), nn_rows=out["stats"]["nn_evals"])
+        return st
+
+    def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0, ref_quirks=True, first_game_id=0, max_steps=0, fetch=True, invariant_nn=False):
+        from oracle import oracle as orc
+        ocfg = orc.MctsCfg(iterations=cfg.iterations, c=cfg.c, round_limit=cfg.round_limit, dir_alpha=cfg.dir_alpha, dir_eps=cfg.dir_eps)
+        out = orc.self_play_parallel(1, n_games, ocfg, temperature, seed, orc.hash_eval_fn(), orc.game(1), ref_quirks=1 if ref_quirks else 0,
+                                     first_game_id=first_game_id, max_steps=max_steps)
+        return {"stats": self._stats(out, n_games if not max_steps else int((out["winners"] != 0).sum()))}
+
+    def self_play_multi(self, batches, cfg, temperature=1.25, ref_quirks=True, max_steps=0, fetch=True, invariant_nn=False):
+        return [self.self_play_parallel(n, cfg, temperature, seed, ref_quirks, first, max_steps) for n, first, seed in batches]
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), DIEE_BENCH_BACKEND="gloo")
+    import contextlib
+    import io
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--games", "3", "--iterations", "5", "--pipeline", "2",
+                    "--no-cpu-baseline"], engine_factory=_StubEngine)
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_main_on_two_gloo_ranks(oracle):
+    """the N > 1 branches of bench.py -- init_process_group, the barriers around the timed region, MAX(time) / SUM(counters),
+    the all_gather of per-rank fragment counts, rank 0's line -- executed by bench.main() itself at world size 2"""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 1000
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1].strip() == ""                                    # only rank 0 prints
+    lines = [l for l in res[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                         # ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["metric"] == "self-play games/sec" and d["unit"] == "games/s" and d["vs_baseline"] is None
+    assert d["stats"]["games"] == 2 * 2 * 3                        # ranks x steps x games per rank: the whole job
+    assert abs(d["value"] - d["stats"]["games"] / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    assert len(d["fragments_per_rank"]) == 2 and sum(d["fragments_per_rank"]) == d["stats"]["fragments"]
+    assert min(d["fragments_per_rank"]) > 0 and d["fragments_per_rank"][0] != d["fragments_per_rank"][1]    # different shards
+    assert d["pipelined"]["batches"] == 2 and d["pipelined"]["games"] == 2 * 2 * 3
+    assert d["roofline"] is None and "scale_note" in d             # the stand-in ran no network kernel: nothing sampled
+    assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
+    # the shards are the block partition of the unsharded batch: rank r's games are ids [3r, 3r + 3)
+    cfg = oracle.MctsCfg(iterations=5, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    per_rank = []
+    for r in range(2):
+        tot = 0
+        for i in range(2):
+            o = oracle.self_play_parallel(1, 3, cfg, 1.25, 0xD1EE0001 + 0x9E37 * i, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=1, first_game_id=3 * r)
+            tot += len(o["outcome"])
+        per_rank.append(tot)
+    assert per_rank == d["fragments_per_rank"]

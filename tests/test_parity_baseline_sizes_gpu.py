@@ -1,0 +1,135 @@
+"""Bit-exact parity of the HIP path against the CPU oracle AT BASELINE.json SIZES.
+
+The other search tests hold the engine to the oracle on tens to hundreds of roots for a handful of iterations; these
+run the geometry the metric is quoted on:
+
+  * diee_mcts_batch vs oracle.alpha_mcts_parallel (alpha_mcts.rs:91-202) at 1024 roots x iterations = 100 (configs[1])
+    and 1024 x 400 (configs[2], per GPU), roots = 1/3 opening, 1/3 middle game, 1/3 bear-off (off >= 11), so that
+    terminal leaves and the stale `selected_nodes_idxs` slots (Q14) fire at full batch size, quirks on and off;
+  * the same at 900 roots, where the engine COMPACTS the evaluation (k_row_map: rows of slots whose leaf was terminal
+    are not evaluated above 256 live games; 929 ... 1024 run plain) -- compaction held to the oracle, not to itself;
+  * diee_self_play vs oracle.self_play_parallel (alpha_parallel.rs:101-231): 1024 games played TO COMPLETION, the one
+    run that crosses every network dispatch band (k_tower16<4,8,3> -> <4,8,6> -> <2,8,9> -> k_tower_cl<8,4> ... <1,8>)
+    with the compaction switching off at 256 live games; ps / state / outcome / game / order and every counter equal.
+
+The oracle's evaluator is the engine's own ResNet called back through diee_nn_forward on the same batch the reference
+would push (all N slots), so both sides see identical priors and values; everything else is the oracle's C restatement
+of the reference's loops.  The C oracle needs 1.6 s (1024 x 100) / 6 s (1024 x 400) / ~15 s (self-play) on one core."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xD1EE0001
+COUNTERS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    yield e
+    e.close()
+
+
+def gpu_eval(eng, oracle):
+    def fn(states_u8):
+        return eng.forward_t(states_u8.view(oracle.BG_STATE).reshape(-1))
+    return oracle.make_eval(fn, 1352)
+
+
+def cfgs(oracle, iters, **kw):
+    import diee_amd
+    d = dict(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25); d.update(kw)
+    return oracle.MctsCfg(**d), diee_amd.MctsConfig(**d)
+
+
+def mixed_roots(oracle, n):
+    """n roots: a third from the first plies of games, a third from the middle game, a third bearing off"""
+    walk = oracle.random_walk_states(2024, 160)
+    off = walk["off"].max(axis=1)
+    third = n // 3
+    late = walk[off >= 11][:n - 2 * third]
+    mid = walk[off == 0][200:200 + third * 20:20]
+    opening = walk[:third]
+    states = np.concatenate([opening, mid, late])
+    assert len(states) == n and len(late) == n - 2 * third
+    return states
+
+
+def run_both(eng, oracle, states, iters, quirks, step=0):
+    n = len(states)
+    ocfg, gcfg = cfgs(oracle, iters)
+    gids = np.arange(7, 7 + n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 11
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, step, gids, rds, quirks)
+    r = eng.alpha_mcts_parallel(states, gcfg, SEED, step, gids, rds, ref_quirks=bool(quirks))
+    return roots, probs, ostats.as_dict(), r
+
+
+def assert_search_equal(roots, probs, os_, r):
+    assert (r["n_children"] == np.array([len(x["children"]) for x in roots], dtype=np.uint32)).all()
+    assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all()
+    assert (r["probs"].view(np.uint32) == probs.view(np.uint32)).all(), np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max()
+    for key in COUNTERS:
+        assert r["stats"][key] == os_[key], (key, r["stats"][key], os_[key])
+    assert r["stats"]["illegal_decodes"] == 0 and os_["code_collisions"] == 0
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+@pytest.mark.parametrize("n,iters", [(1024, 100), (1024, 400)], ids=["config2_1024x100", "config3_1024x400"])
+def test_mcts_batch_bit_exact_at_baseline_size(eng, oracle, n, iters, quirks):
+    roots, probs, os_, r = run_both(eng, oracle, mixed_roots(oracle, n), iters, quirks)
+    assert_search_equal(roots, probs, os_, r)
+    assert os_["nn_evals"] == (iters + 1) * n
+    assert os_["terminal_hits"] > iters * n // 8                 # the bear-off third keeps hitting terminal leaves ...
+    assert os_["depth_sum"] > 2 * os_["selections"]              # ... and the search goes below the first level
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+@pytest.mark.parametrize("n,iters", [(900, 100), (600, 40), (300, 40)], ids=["900x100", "600x40", "300x40"])
+def test_compacted_evaluation_bit_exact_vs_oracle(eng, oracle, n, iters, quirks):
+    """257 ... 928 roots: the engine evaluates only the slots whose selected leaf is not terminal (row map built on the
+    device, up to three tower launches that size themselves from it), the oracle pushes every slot like the reference"""
+    roots, probs, os_, r = run_both(eng, oracle, mixed_roots(oracle, n), iters, quirks, step=3)
+    assert_search_equal(roots, probs, os_, r)
+    assert r["stats"]["nn_rows"] < r["stats"]["nn_evals"]        # the compaction really skipped rows ...
+    assert r["stats"]["nn_rows"] >= r["stats"]["nn_evals"] - os_["terminal_hits"]      # ... at most one per terminal selection
+
+
+def test_self_play_1024_games_to_completion_bit_exact(eng, oracle):
+    """config-2 batch size, iterations = 8: ~0.9 M selections; the live count falls from 1024 to 1 through every tower
+    dispatch band (and through the compaction's on / off threshold at 256)"""
+    n, iters = 1024, 8
+    ocfg, gcfg = cfgs(oracle, iters)
+    ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED + 11, gpu_eval(eng, oracle), None, ref_quirks=1, first_game_id=3000)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 11, ref_quirks=True, first_game_id=3000)
+    assert out["stats"]["move_steps"] == ref["steps"] > 150       # the long tail of a batch is in
+    assert len(out["outcome"]) == len(ref["outcome"]) > 50 * n
+    assert (out["game"] == ref["game"]).all()                      # order of the records included
+    assert (out["outcome"] == ref["outcome"]).all()
+    assert (out["state"].view(np.uint32) == ref["state"].view(np.uint32)).all()
+    assert (out["ps"].view(np.uint32) == ref["ps"].view(np.uint32)).all()
+    for key in COUNTERS[:-1]:
+        assert out["stats"][key] == ref["stats"][key], key
+    assert out["stats"]["plies"] == int(ref["plies"].sum())
+    assert out["stats"]["games"] == n and out["stats"]["fragments"] == len(out["outcome"])
+    assert out["stats"]["illegal_decodes"] == 0 == ref["stats"]["illegal_decodes"]
+    assert out["stats"]["nn_rows"] < out["stats"]["nn_evals"]     # compaction was live while > 256 games were
+    assert set(np.unique(out["outcome"])) <= {-1, 1}               # nobody reached the 400-round limit
+
+
+def test_self_play_1024_games_round_limit_bit_exact(eng, oracle):
+    """the same batch size under a round limit most games hit (Q18 double flush, outcome 0 records, Q19 round counting)"""
+    n, iters = 1024, 4
+    ocfg, gcfg = cfgs(oracle, iters, round_limit=30)
+    for quirks in (1, 0):
+        ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED + 12, gpu_eval(eng, oracle), None, ref_quirks=quirks)
+        out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 12, ref_quirks=bool(quirks))
+        assert out["stats"]["move_steps"] == ref["steps"]
+        assert (out["game"] == ref["game"]).all() and (out["outcome"] == ref["outcome"]).all()
+        assert (out["state"].view(np.uint32) == ref["state"].view(np.uint32)).all()
+        assert (out["ps"].view(np.uint32) == ref["ps"].view(np.uint32)).all()
+        for key in COUNTERS[:-1]:
+            assert out["stats"][key] == ref["stats"][key], key
+        assert (out["outcome"] == 0).any()
