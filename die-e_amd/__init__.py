@@ -44,6 +44,7 @@ EXPORTS = [
     "diee_self_play_multi", "diee_set_invariant_nn", "diee_train_pack_conv3x3", "diee_train_pack_conv3x3_multi",
     "diee_train_conv3x3", "diee_train_im2col3x3",
     "diee_train_scratch_floats", "diee_train_bn_relu_fwd", "diee_train_bn_relu_bwd", "diee_train_colsum",
+    "diee_train_set_bn_coop", "diee_train_bn_coop_timeouts",
     "diee_train_wgrad_scratch_floats", "diee_train_wgrad3x3",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
     "diee_bg_planes", "diee_det_pow",
@@ -135,6 +136,8 @@ def load_library(path=None):
     L.diee_train_bn_relu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, C.c_int, vp, vp]; L.diee_train_bn_relu_fwd.restype = C.c_int
     L.diee_train_bn_relu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]; L.diee_train_bn_relu_bwd.restype = C.c_int
     L.diee_train_colsum.argtypes = [vp, vp, C.c_int, vp, vp]; L.diee_train_colsum.restype = C.c_int
+    L.diee_train_set_bn_coop.argtypes = [C.c_int]; L.diee_train_set_bn_coop.restype = C.c_int
+    L.diee_train_bn_coop_timeouts.argtypes = [C.c_int]; L.diee_train_bn_coop_timeouts.restype = C.c_int
     L.diee_train_wgrad_scratch_floats.argtypes = []; L.diee_train_wgrad_scratch_floats.restype = C.c_size_t
     L.diee_train_wgrad3x3.argtypes = [vp, vp, vp, C.c_int, vp, vp]; L.diee_train_wgrad3x3.restype = C.c_int
     L.diee_free_fragments.argtypes = [vp]; L.diee_free_fragments.restype = None

@@ -21,7 +21,7 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch
 
-from . import BG_ACTIONS, BG_PLANES, Engine, MctsConfig, random_weights
+from . import BG_ACTIONS, BG_PLANES, ERR_ARG, ERR_HIP, DieeError, Engine, MctsConfig, random_weights
 from . import ot as _ot
 
 # PyTorch bundles its own HIP runtime; it has to initialise BEFORE libdiee.so's (system ROCm) runtime does,
@@ -172,6 +172,10 @@ class AlphaZero:
             dev = torch.device(self.device)
             self.ddp = DDP(self.model, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()]
                            if dev.type == "cuda" else None)
+            if dev.type == "cuda":
+                # a data-parallel step overlaps RCCL's all-reduce kernels with the backward pass: the one-launch BatchNorm
+                # passes (every workgroup resident at once, meeting on a device counter) would share the CUs with them
+                self._set_bn_coop(False)
         on_gpu = torch.device(self.device).type == "cuda"
         # DIEE_TRAIN=torch: the all-PyTorch fp32 step (MIOpen convolutions); default on a GPU: the tower on the engine's kernels
         self.model.engine_tower = on_gpu and os.environ.get("DIEE_TRAIN", "engine") != "torch"
@@ -217,7 +221,23 @@ class AlphaZero:
         for _ in range(K):
             self.calls += 1
             batches.append((n, self.rank * n, self.seed + 0x9E3779B1 * self.calls))
-        outs = self.engine.self_play_multi(batches, self.mcts_config, self.config.temperature, ref_quirks=True)
+        # a call takes at most 64 batches (kMaxSegments) and its fragment arena grows with the batches in flight
+        # (games x (round_limit + 2) x 6 KB: 2.5 GB per 1024-game batch): groups within both limits, one call per group
+        per_batch = n * (self.mcts_config.round_limit + 2) * (BG_ACTIONS + BG_PLANES) * 4 + n * (self.mcts_config.iterations + 1) * 128 * 56
+        budget = int(float(os.environ.get("DIEE_PIPELINE_GB", "96")) * 2 ** 30)
+        group = max(1, min(64, budget // max(per_batch, 1)))
+        outs = []
+        for g0 in range(0, K, group):
+            part = batches[g0:g0 + group]
+            try:
+                outs += self.engine.self_play_multi(part, self.mcts_config, self.config.temperature, ref_quirks=True)
+            except DieeError as e:
+                if e.status not in (ERR_ARG, ERR_HIP) or len(part) == 1:
+                    raise
+                self.log(f"[self-play] {len(part)} batches side by side failed ({e}); playing them one after the other")
+                for nb, first, seed in part:
+                    outs.append(self.engine.self_play_parallel(nb, self.mcts_config, self.config.temperature, seed=seed,
+                                                               ref_quirks=True, first_game_id=first))
         self.last_stats = outs[-1]["stats"]
         return [{"outcome": o["outcome"], "ps": o["ps"], "state": o["state"]} for o in outs]
 
@@ -391,28 +411,60 @@ class AlphaZero:
             if not self._graph_selfcheck(g, mem_st[i0].reshape(-1, 6, 4, 6), mem_ps[i0], mem_oc[i0].unsqueeze(1)):
                 self.log("[train] the captured step does not reproduce the eager loss: training eagerly")
                 use_graph = False
-        for i, b0 in enumerate(range(0, n_steps * bs, bs)):                     # :205-206
-            if on_gpu:
-                idx = perm_t[b0:min(b0 + bs, n)]
-                st = mem_st[idx].reshape(-1, 6, 4, 6); ps = mem_ps[idx]; oc = mem_oc[idx].unsqueeze(1)
-            else:
-                idx = perm[b0:b0 + bs]
-                st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6)
-                ps = torch.from_numpy(memory["ps"][idx]); oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1)
-            if use_graph and len(idx) == bs:
-                g["st"].copy_(st); g["ps"].copy_(ps); g["oc"].copy_(oc)
-                g["graph"].replay()
-                loss_buf[i] = g["loss"].detach()
-            else:
-                loss = self._loss(net, st, ps, oc)
-                self.optimizer.zero_grad(set_to_none=True)                      # (the captured step keeps its own gradient tensors)
-                loss.backward()
-                self.optimizer.step()
-                loss_buf[i] = loss.detach()
-        losses = loss_buf[:n_steps].tolist()
+        # The reference asserts on the loss BEFORE backward / step of every batch (alphazero.rs:248-255); here the losses are
+        # read back once per epoch (no host sync per step), so the epoch runs on a snapshot: a non-finite loss anywhere in it
+        # puts parameters, BatchNorm statistics and Adam's moments back to where the epoch started before anything is raised --
+        # a caller that catches the exception holds the model it had, not one a NaN went through Adam on.
+        snap = self._snapshot()
+
+        def run_epoch(use_graph):
+            for i, b0 in enumerate(range(0, n_steps * bs, bs)):                 # :205-206
+                if on_gpu:
+                    idx = perm_t[b0:min(b0 + bs, n)]
+                    st = mem_st[idx].reshape(-1, 6, 4, 6); ps = mem_ps[idx]; oc = mem_oc[idx].unsqueeze(1)
+                else:
+                    idx = perm[b0:b0 + bs]
+                    st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6)
+                    ps = torch.from_numpy(memory["ps"][idx]); oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1)
+                if use_graph and len(idx) == bs:
+                    g["st"].copy_(st); g["ps"].copy_(ps); g["oc"].copy_(oc)
+                    g["graph"].replay()
+                    loss_buf[i] = g["loss"].detach()
+                else:
+                    loss = self._loss(net, st, ps, oc)
+                    self.optimizer.zero_grad(set_to_none=True)                  # (the captured step keeps its own gradient tensors)
+                    loss.backward()
+                    self.optimizer.step()
+                    loss_buf[i] = loss.detach()
+            return loss_buf[:n_steps].tolist()
+
+        losses = run_epoch(use_graph)
         if not np.isfinite(losses).all():
-            raise FloatingPointError("Total loss is nan or inf!")              # :248-255
+            self._restore(snap)
+            # a starved one-launch BatchNorm pass (something else held CUs: another process, a collective) writes NaN
+            # statistics and raises its timeout flag: re-run the epoch once on the three-launch passes before giving up
+            timed_out = self._bn_coop_timeouts(clear=True) if on_gpu else 0
+            if timed_out > 0:
+                self.log(f"[train] a one-launch BatchNorm pass timed out (flags {timed_out}): epoch restored and repeated on the three-launch passes")
+                self._set_bn_coop(False)
+                self._graph = None                                              # the captured step holds the one-launch kernels
+                losses = run_epoch(False)
+                if not np.isfinite(losses).all():
+                    self._restore(snap)
+                    raise FloatingPointError("Total loss is nan or inf!")
+            else:
+                raise FloatingPointError("Total loss is nan or inf!")          # :248-255
         return losses
+
+    @staticmethod
+    def _bn_coop_timeouts(clear=True):
+        from . import load_library
+        return int(load_library().diee_train_bn_coop_timeouts(1 if clear else 0))
+
+    @staticmethod
+    def _set_bn_coop(on):
+        from . import load_library
+        load_library().diee_train_set_bn_coop(1 if on else 0)
 
     def sync_engine(self):
         """fold the trained weights back into the HIP engine (BN running statistics included)"""

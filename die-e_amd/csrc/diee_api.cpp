@@ -279,6 +279,8 @@ diee_status diee_train_wgrad3x3(const void* x, const void* dy, float* dw, int bo
     launch_wgrad3x3((hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy, scratch, dw, boards);
     return hipGetLastError() == hipSuccess ? DIEE_OK : DIEE_ERR_HIP;
 }
+diee_status diee_train_set_bn_coop(int on) { bn_coop_set(on); return DIEE_OK; }
+int diee_train_bn_coop_timeouts(int clear) { return bn_coop_poll_timeouts(clear); }
 diee_status diee_train_colsum(const void* a, float* out, int rows, float* scratch, void* stream) {
     if (!a || !out || !scratch || rows <= 0) return DIEE_ERR_ARG;
     launch_colsum((hipStream_t)stream, (const uint16_t*)a, scratch, out, rows);

@@ -44,6 +44,9 @@ void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, 
 void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, const uint16_t* x, const float* gamma,
                         const float* mean, const float* invstd, float* partial, float* dgamma, float* dbeta, uint16_t* dx,
                         uint16_t* dres, float* dx_colsum /*[256] or nullptr*/, int M);
+void bn_coop_set(int on);
+int bn_coop_get();
+int bn_coop_poll_timeouts(int clear);     // bit 0 forward, bit 1 backward pass timed out since the last clear; -1: query failed
 size_t wgrad_scratch_floats();
 void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards);
 void launch_colsum(hipStream_t st, const uint16_t* a, float* partial, float* out, int M);

@@ -6,6 +6,8 @@
 // 3 MB sweep each.  Reductions are two-stage (per-stripe partials, then every workgroup folds the partials in a fixed
 // order): deterministic, no atomics.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -455,32 +457,80 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_coop(const uint16_t* __restrict
     if (t < 256) dx_colsum[t] = ok2_s ? cs : __builtin_nanf("");
 }
 
-// four words per device: the counters of grid_meet (and the timeout flags); how many 1024-thread workgroups fit at once
-static uint32_t* bn_sync_words(int& resident) {
-    static uint32_t* w[16] = {nullptr};
-    static int res[16] = {0};
-    static std::mutex mu;                               // two host threads may take their first training step together
-    std::lock_guard<std::mutex> lock(mu);
+// Barrier words of the one-launch passes: one set of 16 words (64 B) PER (device, stream) -- two passes running at once on
+// different streams of one device would otherwise mix their arrivals on shared words and release each other early on
+// partials that are not written yet.  Word 3 of a set collects its timeouts (bit 0 forward, bit 1 backward): the host reads
+// and clears them with bn_coop_poll_timeouts().  `resident`: how many 1024-thread workgroups the device holds at once.
+namespace {
+constexpr int kBnSets = 16, kBnSetWords = 32;         // 16 streams per device, one 128-byte line each
+struct BnDev { uint32_t* pool = nullptr; hipStream_t owner[kBnSets]; int n = 0; int resident = 0; bool failed = false; };
+BnDev g_bn_dev[16];
+std::mutex g_bn_mu;                                   // two host threads may take their first training step together
+std::atomic<int> g_bn_coop_on{-1};                    // -1: not decided yet (DIEE_BN_COOP), 0 off, 1 on
+}
+static uint32_t* bn_sync_words(hipStream_t st, int& resident) {
+    std::lock_guard<std::mutex> lock(g_bn_mu);
     int dev = 0;
     resident = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!w[dev]) {
+    BnDev& D = g_bn_dev[dev];
+    if (D.failed) return nullptr;
+    if (!D.pool) {
+        // the whole pool is allocated and zeroed at the first pass on the device (an eager step: the training loop warms up
+        // before it captures), so that handing a set to a new stream later -- possibly inside a capture -- is pure host work
         uint32_t* p = nullptr;
-        if (hipMalloc((void**)&p, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+        if (hipMalloc((void**)&p, sizeof(uint32_t) * kBnSets * kBnSetWords) != hipSuccess) { (void)hipGetLastError(); D.failed = true; return nullptr; }
+        if (hipMemset(p, 0, sizeof(uint32_t) * kBnSets * kBnSetWords) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(p); D.failed = true; return nullptr;
+        }
         int per_cu_f = 0, per_cu_b = 0, cus = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, (const void*)k_bn_fwd_coop, 1024, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)k_bn_bwd_coop, 1024, 0);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        res[dev] = (per_cu_f > 0 && per_cu_b > 0) ? cus : 0;     // one workgroup per CU is all the launcher counts on
-        w[dev] = p;
+        D.resident = (per_cu_f > 0 && per_cu_b > 0) ? cus : 0;     // one workgroup per CU is all the launcher counts on
+        D.pool = p;
     }
-    resident = res[dev];
-    return w[dev];
+    resident = D.resident;
+    for (int i = 0; i < D.n; ++i) if (D.owner[i] == st) return D.pool + i * kBnSetWords;
+    if (D.n >= kBnSets) return nullptr;                 // a caller cycling through streams: the three-launch passes take it
+    D.owner[D.n] = st;
+    return D.pool + (D.n++) * kBnSetWords;
 }
 static bool bn_coop_enabled() {
-    static const bool on = [] { const char* e = getenv("DIEE_BN_COOP"); return !(e && e[0] == '0'); }();
-    return on;
+    int v = g_bn_coop_on.load();
+    if (v < 0) {
+        const char* e = getenv("DIEE_BN_COOP");
+        v = !(e && e[0] == '0') ? 1 : 0;
+        g_bn_coop_on.store(v);
+    }
+    return v != 0;
+}
+// runtime switch (diee_train_set_bn_coop): the one-launch passes count on having the device to themselves -- callers that
+// share it (RCCL kernels of a DDP step, a second rank or process on the GPU) turn them off
+void bn_coop_set(int on) { g_bn_coop_on.store(on ? 1 : 0); }
+int bn_coop_get() { return bn_coop_enabled() ? 1 : 0; }
+// timeouts of the one-launch passes on the current device since the last clear (bit 0 forward, bit 1 backward); blocks
+// until the device is idle.  -1: the query itself failed.
+int bn_coop_poll_timeouts(int clear) {
+    std::lock_guard<std::mutex> lock(g_bn_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+    BnDev& D = g_bn_dev[dev];
+    if (!D.pool) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
+    uint32_t w[kBnSets * kBnSetWords];
+    if (hipMemcpy(w, D.pool, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    uint32_t all = 0;
+    bool dirty = false;
+    for (int i = 0; i < D.n; ++i) {
+        const uint32_t* q = w + i * kBnSetWords;
+        all |= q[3];
+        dirty = dirty || q[3] || q[0] || q[2];          // a starved meeting leaves arrivals behind: re-arm the sets
+    }
+    if (clear && dirty) {
+        if (hipMemset(D.pool, 0, sizeof w) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
+    }
+    return (int)all;
 }
 
 int train_stripes(int M) { return (M + kStripe - 1) / kStripe; }
@@ -492,7 +542,7 @@ void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, 
     const int S = train_stripes(M);
     float* coef = partial + (size_t)S * 768;
     int resident = 0;
-    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(resident) : nullptr;
+    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(st, resident) : nullptr;
     if (bar && S <= resident) {
         hipLaunchKernelGGL(k_bn_fwd_coop, dim3(S), dim3(1024), 0, st, x, res, gamma, beta, partial, save_mean, save_invstd, run_mean,
                            run_var, momentum, eps, y, M, bar);
@@ -509,7 +559,7 @@ void launch_bn_relu_bwd(hipStream_t st, const uint16_t* dy, const uint16_t* y, c
     const int S = train_stripes(M);
     float* coef = partial + (size_t)S * 768;
     int resident = 0;
-    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(resident) : nullptr;
+    uint32_t* bar = bn_coop_enabled() ? bn_sync_words(st, resident) : nullptr;
     if (bar && S <= resident) {
         hipLaunchKernelGGL(k_bn_bwd_coop, dim3(S), dim3(1024), 0, st, dy, y, x, gamma, mean, invstd, partial, partial + (size_t)S * 512,
                            dgamma, dbeta, dx, dres, dx_colsum, M, bar);

@@ -39,7 +39,20 @@ def _chk(st, what):
         raise RuntimeError(f"{what} failed with diee status {st}")
 
 
-_dx_colsum = [None, None]              # (data_ptr of the dx a batch-norm backward just wrote, its column sums): the conv bias gradient
+# The bias gradient of a convolution is the column sum of its output gradient, and the batch-norm backward that WRITES that
+# gradient (dx) sums its columns on the way out.  Hand-over: the entry keeps a strong reference to dx itself -- while it
+# exists the caching allocator cannot give dx's address to another tensor, so "same data_ptr, same shape, same version
+# counter" means "this very dx, unmodified" -- and EVERY convolution backward clears it, whether it matched or not.
+_dx_colsum = {"dx": None, "colsum": None, "version": None}
+
+
+def _take_colsum(dy):
+    e = dict(_dx_colsum)
+    _dx_colsum["dx"] = _dx_colsum["colsum"] = _dx_colsum["version"] = None
+    dx = e["dx"]
+    if dx is None or dx.data_ptr() != dy.data_ptr() or dx.shape != dy.shape or dx.dtype != dy.dtype or dx._version != e["version"]:
+        return None
+    return e["colsum"]
 
 
 class Conv3x3Tok(torch.autograd.Function):
@@ -85,9 +98,9 @@ class Conv3x3Tok(torch.autograd.Function):
                 dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
                 scratch = torch.empty(int(L.diee_train_wgrad_scratch_floats()), dtype=torch.float32, device=x.device)
                 _chk(L.diee_train_wgrad3x3(_ptr(x), _ptr(dy), _ptr(dw), boards, _ptr(scratch), _stream()), "wgrad")
-        if ctx.needs_input_grad[2] and _dx_colsum[0] == dy.data_ptr():
-            db = _dx_colsum[1]                                   # the batch-norm backward that wrote dy summed its columns already
-            _dx_colsum[0] = _dx_colsum[1] = None
+        ready = _take_colsum(dy)                                 # always consumed: a stale entry can never meet a later dy
+        if ctx.needs_input_grad[2] and ready is not None:
+            db = ready                                           # the batch-norm backward that wrote dy summed its columns already
         elif ctx.needs_input_grad[2]:
             db = torch.empty(256, dtype=torch.float32, device=x.device)
             scratch = torch.empty(int(L.diee_train_scratch_floats(x.shape[0])), dtype=torch.float32, device=x.device)
@@ -133,7 +146,7 @@ class BnReluTok(torch.autograd.Function):
         _chk(L.diee_train_bn_relu_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
                                       _ptr(dx), _ptr(dres) if dres is not None else None, _ptr(colsum), M, _ptr(scratch), _stream()),
              "bn_relu backward")
-        _dx_colsum[0], _dx_colsum[1] = dx.data_ptr(), colsum     # for the backward of the convolution in front (next in autograd order)
+        _dx_colsum["dx"], _dx_colsum["colsum"], _dx_colsum["version"] = dx, colsum, dx._version   # for the convolution in front (next in autograd order)
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 

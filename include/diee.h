@@ -201,14 +201,23 @@ diee_status diee_train_im2col3x3(const void* x_bf16, void* col_bf16 /*[boards*24
 /* BatchNorm2d in training mode over the rows (= batch x 4 x 6) fused with the residual add and the ReLU of
  * ResBlock::forward_t (nnet.rs:24-34): y = relu(gamma * (x - mean) / sqrt(var + eps) + beta [+ res]); updates the running
  * statistics (momentum, unbiased variance) when given.  scratch: diee_train_scratch_floats(rows) floats.  Deterministic.
- * Each pass is ONE launch while rows / 64 workgroups can be resident together (they meet on a device counter: do not run two
- * of these passes concurrently on different streams of one device), three launches above that or with DIEE_BN_COOP=0.
+ * Each pass is ONE launch while rows / 64 workgroups can be resident together (they meet on a device counter, one set of
+ * counters per stream), three launches above that, with DIEE_BN_COOP=0 or after diee_train_set_bn_coop(0).
  * dx_colsum, when given, receives the column sums of dx: the bias gradient of the convolution that produced x. */
 size_t      diee_train_scratch_floats(int rows);
 diee_status diee_train_bn_relu_fwd(const void* x_bf16, const void* res_bf16 /*or NULL*/, const float* gamma, const float* beta,
                                    float* running_mean /*or NULL*/, float* running_var, float momentum, float eps,
                                    float* save_mean /*[256]*/, float* save_invstd /*[256]*/, void* y_bf16, int rows,
                                    float* scratch, void* stream);
+/* The one-launch passes count on having the device to themselves (their workgroups wait for each other inside the launch;
+ * every stream has its own barrier words, the waits are bounded and a starved pass writes NaN statistics instead of hanging).
+ * diee_train_set_bn_coop(0) selects the three-launch passes for the rest of the process (callers whose step shares the GPU:
+ * RCCL kernels of a data-parallel step, a second rank or process; DIEE_BN_COOP=0 does the same from the environment).
+ * diee_train_bn_coop_timeouts(clear): waits for the device, then returns the timeouts since the last clear (bit 0 forward,
+ * bit 1 backward; -1 = the query failed) and, with clear != 0, re-arms the barrier words -- the caller then repeats the step
+ * (die-e_amd/alphazero.py restores its pre-epoch snapshot and re-runs the epoch on the three-launch passes). */
+diee_status diee_train_set_bn_coop(int on);
+int         diee_train_bn_coop_timeouts(int clear);
 /* its backward: dx (to the convolution), dres (= dy masked by the ReLU, to the skip connection; may be NULL), dgamma, dbeta */
 diee_status diee_train_bn_relu_bwd(const void* dy_bf16, const void* y_bf16, const void* x_bf16, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,

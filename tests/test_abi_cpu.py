@@ -62,6 +62,29 @@ def test_header_compiles_as_c_and_layouts_match_the_ctypes_mirror(tmp_path):
 
 
 
+def test_rust_binding_in_integration_md_is_generated_from_the_header():
+    """INTEGRATION.md's `extern "C"` block is scripts/gen_rust_ffi.py's output for today's include/diee.h: every diee_*
+    prototype of the header appears in it with the same arity (counted here by a parser of its own, not the generator's)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "scripts", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)]
+    assert block.strip() == ("```rust\n" + gen.generate() + "```").strip(), "run `python scripts/gen_rust_ffi.py --update`"
+    # independent arity count: C side = commas at depth 0 of the parameter list, Rust side = `name:` bindings
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "diee.h")).read(), flags=re.S)
+    c_arity = {}
+    for m in re.finditer(r"\b(diee_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr):
+        args = m.group(2).strip()
+        c_arity[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rust_arity = {m.group(1): len(re.findall(r"\b\w+\s*:", m.group(2))) for m in re.finditer(r"pub fn (diee_\w+)\(([^)]*)\)", block)}
+    assert sorted(c_arity) == header_symbols() and len(c_arity) >= 29
+    assert rust_arity == c_arity
+    for st in ("DieeBgState", "DieeMctsCfg", "DieeStats", "DieeFragments", "DieeBatch", "DieeCtx"):
+        assert f"pub struct {st}" in block or f"pub enum {st}" in block
+    assert block.count("pub games: u64") == 1 and len(re.findall(r"^    pub \w+: (?:u64|f64),$", block, flags=re.M)) >= 27 + 1
+
+
 def test_state_struct_is_32_bytes_and_matches_the_oracle(oracle):
     assert diee_amd.BG_STATE.itemsize == 32 == oracle.BG_STATE.itemsize
     assert diee_amd.BG_STATE.fields.keys() == oracle.BG_STATE.fields.keys()

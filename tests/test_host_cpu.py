@@ -210,3 +210,30 @@ def test_train_reshuffles_every_epoch(oracle):
                      train_device="cpu", quiet=True)
     p1 = a.shuffle_rng.permutation(32); p2 = a.shuffle_rng.permutation(32)
     assert (p1 != p2).any()
+
+
+def test_train_puts_the_model_back_when_a_loss_is_not_finite(oracle):
+    """alphazero.rs:248-255 asserts on the loss before backward / step; train() reads the losses back once per epoch, so it
+    runs the epoch on a snapshot: after a non-finite loss the parameters, the BatchNorm statistics and Adam's moments are
+    those the epoch started from, and only then is FloatingPointError raised"""
+    import torch
+    blob = diee_amd.random_weights(0)
+    conf = az.AlphaZeroConfig(1.25, 1, 1, 1, 8, 3)
+    a = az.AlphaZero(None, conf, diee_amd.MctsConfig.default(4), az.OptimizerParams(1e-4, 1e-3), blob=blob,
+                     train_device="cpu", quiet=True)
+    mem = small_memory(oracle)
+    good = {k: v[:16].copy() for k, v in mem.items()}
+    a.train(good)                                                                # Adam now holds moments, BatchNorm has moved
+    before = {k: v.clone() for k, v in a.model.state_dict().items()}
+    opt_before = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in a.optimizer.state.items()}
+    bad = {k: v.copy() for k, v in good.items()}
+    bad["ps"][11, 3] = np.inf                                                    # the second batch of the epoch
+    with pytest.raises(FloatingPointError):
+        a.train(bad)
+    after = a.model.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    for p, st in a.optimizer.state.items():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, opt_before[id(p)][k]), k
+    assert np.isfinite(a.train(good)).all()                                      # and training goes on from there

@@ -115,7 +115,7 @@ for rep in range(3):
     rm, rv = torch.zeros(256, device="cuda"), torch.ones(256, device="cuda")
     y = ops.BnReluTok.apply(x, g, b, res, rm, rv, 0.1, 1e-5)
     gr = torch.autograd.grad(y, (x, g, b, res), dy)
-    outs.append([y.detach().float().cpu(), rm.cpu(), rv.cpu()] + [t.float().cpu() for t in gr] + [ops._dx_colsum[1].cpu()])
+    outs.append([y.detach().float().cpu(), rm.cpu(), rv.cpu()] + [t.float().cpu() for t in gr] + [ops._dx_colsum["colsum"].cpu()])
 for o in outs[1:]:
     assert all(torch.equal(a, c) for a, c in zip(o, outs[0])), "not deterministic"
 torch.save(outs[0], sys.argv[1])
@@ -220,3 +220,45 @@ def test_alphazero_train_engine_backend_with_and_without_graph(oracle, monkeypat
     # fp32 PyTorch step vs bf16 engine step: same trajectory within mixed-precision noise
     assert np.allclose(g[0], t[0], rtol=5e-2), (g[0], t[0])
     print(f"[train-parity] losses graph {np.round(g[0], 4).tolist()}\\n               torch {np.round(t[0], 4).tolist()}")
+
+
+def test_bn_one_launch_passes_on_two_streams_and_the_runtime_switch():
+    """every stream has its own barrier words (two concurrent one-launch passes must not release each other early): two
+    streams running the passes side by side give, bit for bit, what each gives alone; no pass times out
+    (diee_train_bn_coop_timeouts); diee_train_set_bn_coop(0) selects the three-launch passes at run time"""
+    import importlib
+    import torch
+    ops = importlib.import_module("die-e_amd.train_ops")
+    L = diee_amd.load_library()
+    torch.manual_seed(5)
+    M = 6144
+
+    def inputs(k):
+        g = torch.Generator(device="cuda").manual_seed(100 + k)
+        x = (torch.randn(M, 256, device="cuda", generator=g) * 1.1).to(torch.bfloat16)
+        return x, torch.rand(256, device="cuda", generator=g), torch.randn(256, device="cuda", generator=g)
+
+    def fwd(x, g, b):
+        return ops.BnReluTok.apply(x, g, b, None, None, None, 0.1, 1e-5)
+
+    ins = [inputs(0), inputs(1)]
+    alone = [fwd(*i).float().cpu() for i in ins]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(20):                                     # back to back on both streams: the passes overlap on the device
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(fwd(*ins[k]))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for y in outs[k]:
+            assert torch.equal(y.float().cpu(), alone[k])
+    assert L.diee_train_bn_coop_timeouts(1) == 0
+    try:
+        L.diee_train_set_bn_coop(0)
+        three = fwd(*ins[0]).float().cpu()
+        assert rel(three, alone[0]) < 2e-3
+    finally:
+        L.diee_train_set_bn_coop(1)
+    assert torch.equal(fwd(*ins[0]).float().cpu(), alone[0])
