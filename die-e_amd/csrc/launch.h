@@ -34,8 +34,11 @@ void nn_set_tower_dbg(unsigned long long* p);
 // `err` gets bit 2 set if a cluster wait timed out.  false = not launched (grid would not be co-resident).
 constexpr int kClusterMaxGroups = 64;
 // `states` non-null: the init block runs inside the launch (winit / binit = its fragments and bias); X then holds no input
+// `whead` non-null: the head convs (two 32-column slices, wconv[39]) and the policy FC run inside the launch too: hv / logits are written
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
-                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit);
+                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
+                          const void* whead = nullptr, const float* bhead = nullptr, const void* wfc = nullptr, const float* bfc = nullptr,
+                          float* hv = nullptr, float* logits = nullptr);
 // train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 768 + 1280 floats of scratch)
 int train_stripes(int M);
 void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,

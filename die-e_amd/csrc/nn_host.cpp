@@ -148,6 +148,7 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
+    if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
     if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
@@ -282,8 +283,11 @@ void nn_reset_cluster(Engine& e) {
 
 // small batches: the 38 tower layers in one launch (k_tower_cl).  false = no rule takes this batch size, or the grid
 // would not be co-resident on this device: the caller runs the per-layer kernels.
-static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, uint16_t* actX, uint16_t* actH) {
+// hv / logits non-null: the launch runs the head convs and the policy FC too (rows of this chunk)
+static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, uint16_t* actX, uint16_t* actH, float* hv = nullptr,
+                          float* logits = nullptr) {
     const void* winit = W.wconv[0].p; const float* binit = W.bconv[0].p;
+    const void* whead = logits ? W.wconv[39].p : nullptr;
     for (const auto& r : W.cluster_table) {
         if (G > r.max_games) continue;
         if (!W.cl_sync.p) {
@@ -296,19 +300,22 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
             if (bt->engines > 1) {
                 if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
                 else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
-                const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
+                const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
+                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits);
                 if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
                 return ok;
             }
         }
-        return launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit);
+        return launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
+                                    whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits);
     }
     return false;
 }
 
 // the convolutional part of the network (init block, 38-layer tower, head convs) for rows [off, off + G) of the batch:
 // states -> hp / hv.  The tower kernel is picked by G alone (tower_table / cluster_table).
-static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, bool fused_family = false) {
+// Returns true when the launch produced the chunk's logits as well (cluster tower with the heads and the FC inside).
+static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, bool fused_family = false) {
     NetWeights& W = *e.net;
     hipStream_t st = e.stream;
     const void* states_dev = (const uint8_t*)states_all + (size_t)off * 32;
@@ -329,16 +336,17 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     auto init_block = [&] {
         launch_conv3x3(st, 16, 0, (const uint16_t*)states_dev, W.wconv[0].p, W.bconv[0].p, nullptr, actX, nullptr, G, 256);
     };
-    auto cluster = [&](const void* states) {
-        const bool ok = cluster_tower(e, W, G, states, actX, actH);
+    float* logits = W.logits.p + (size_t)off * 1352;
+    auto cluster = [&](const void* states, bool with_heads) {
+        const bool ok = cluster_tower(e, W, G, states, actX, actH, with_heads ? hv : nullptr, with_heads ? logits : nullptr);
         if (ok) W.cluster_used = true;
         return ok;
     };
-    bool done = false, heads_done = false;
+    bool done = false, heads_done = false, fc_done = false;
     if (tgeom < 0 && !W.cluster_table.empty() && W.cluster_init) {
-        // small batches: init block + all 38 layers in ONE launch, 8-workgroup clusters per board group
+        // small batches: init block + all 38 layers (+ head convs + policy FC) in ONE launch, 8-workgroup clusters per board group
         stamp0();
-        if (cluster(states_dev)) { kind = 2; done = true; }
+        if (cluster(states_dev, W.cluster_heads)) { kind = 2; done = true; heads_done = fc_done = W.cluster_heads; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
     if (!done && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
@@ -353,7 +361,7 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (!ev0) stamp0();
         if (tgeom >= 0) {
             launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G);   // all 38 layers, activations stay in LDS
-        } else if (cluster(nullptr)) {
+        } else if (cluster(nullptr, false)) {
             kind = 2;                                                   // (init block launched separately: DIEE_CLUSTER_INIT=0)
         } else {
             kind = 0;
@@ -373,6 +381,7 @@ static void nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, (kind == 1 && tgeom == 8) ? 3 : kind, -1});
     }
     if (!heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
+    return fc_done;
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
@@ -418,9 +427,12 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         main_rows = G / full * full;
         if (W.tower_geometry_for(G - main_rows) == tg) main_rows = G;   // the remainder would take the same kernel
     }
-    nn_conv_chunk(e, states_dev, 0, main_rows);
-    if (main_rows < G) nn_conv_chunk(e, states_dev, main_rows, G - main_rows, true);
-    launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
+    const bool fc_main = nn_conv_chunk(e, states_dev, 0, main_rows);
+    const bool fc_rest = main_rows < G ? nn_conv_chunk(e, states_dev, main_rows, G - main_rows, true) : true;
+    // the policy FC for the rows whose launch did not run it itself (the cluster tower does)
+    if (!fc_main && !fc_rest) launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
+    else if (!fc_main) launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, main_rows);
+    else if (!fc_rest) launch_policy_fc(st, W.hp.p + (size_t)main_rows * 768, W.wfc.p, W.bfc.p, W.logits.p + (size_t)main_rows * 1352, G - main_rows);
     if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
     return false;

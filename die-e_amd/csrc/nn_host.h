@@ -39,6 +39,7 @@ struct NetWeights {
                                     // it run whole multiples in one launch and the remainder in a launch of its own (0: never split)
     bool fused_heads = true;        // the fused tower runs the head convs itself (its output tile never leaves the CU)
     bool cluster_init = true;       // the cluster tower runs the init block itself (every workgroup, for its cluster's boards)
+    bool cluster_heads = true;      // ... and the head convs and the policy FC (an evaluation below 257 boards = cluster launch + k_expand)
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias
     bool loaded = false;

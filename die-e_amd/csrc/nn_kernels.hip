@@ -36,6 +36,13 @@
 #ifndef DIEE_CL_PD
 #define DIEE_CL_PD 0              // cluster tower: LDS prefetch distance in k-steps (0 = by geometry)
 #endif
+#ifndef DIEE_CL_LATE
+#define DIEE_CL_LATE 6            // cluster tower: how many of a layer's 18 next-layer weight fragments per wave are requested AFTER the MFMA loop
+                                  // (in the shadow of the partial-tile reduction) instead of inside it; 0 = all inside (rounds 1-2)
+#endif
+#ifndef DIEE_CL_PRIVATE
+#define DIEE_CL_PRIVATE 1         // cluster tower: every wave stages its own channel columns of the activation tile (no barrier between staging and the MFMA loop)
+#endif
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
@@ -424,6 +431,29 @@ __device__ __forceinline__ void st_coherent16(__amdgpu_buffer_rsrc_t r, int byte
 // (w = 0 writes plain data over unknown leftovers, so that one hand-over uses the counter; w = 37 is the tower output.)
 __device__ __forceinline__ uint32_t tag_of(int w) { return (uint32_t)(((w >> 1) ^ w) & 1) << 15; }
 
+// The rest of the network inside the cluster launch (round 3).  Below 257 boards an evaluation used to be four launches --
+// cluster tower, head convs, policy FC, k_expand -- and every launch boundary is 1.2-1.5 us plus a cold start on a chain
+// that is pure latency (a handful of boards on a 256-CU chip).  With `whead` set the launch goes on after layer 37:
+//   "layer 38" = the two head convolutions (nnet.rs:76-78, 88-90), 64 output columns = two 32-column slices, on the
+//       workgroups of slices 0 (policy, 32 channels) and 1 (value, 3 channels) with the SAME loop body as a tower layer
+//       (k_conv3x3_sk<2, GT, NSPLIT>'s arithmetic: per-layer path = same bits); the tower output reaches them as a
+//       tagged hand-off like any layer (tag in bit 31 of a word, see tag38: bit 15 must end the launch clear);
+//   the policy features (post-ReLU bf16: sign bits free) go to channels 0..31 of the H rows of the group, tagged
+//       tag_of(38) -- H held layer 36 (the other polarity), so the data is its own ready flag once more and the hand-off
+//       to all eight workgroups of the cluster costs one tagged poll; the value features go to hv (nobody in here reads them);
+//   policy FC 768 -> 1352 (nnet.rs:80-85): the cluster's eight workgroups share the 43 output slices, one wave per
+//       slice, k_policy_fc's MFMA sequence per slice (same bits), the slice's first 24 weight fragments requested before
+//       the poll; logits [board][1352] f32.
+struct ClusterHeads {
+    const u32x4* whead;     // [2][144][64] x 16 B: head convs as two 32-column slices (wconv[39]); null = stop after the tower
+    const float* bhead;     // [64]
+    const u32x4* wfc;       // [43][48][64] x 16 B
+    const float* bfc;       // [1376]
+    float* hv;              // [G][72]
+    float* logits;          // [G][1352]
+};
+constexpr int kFcRowStride = 1536 + 16;       // LDS stride of a board's 768 policy features (bank-conflict-free ds_read_b128 over boards)
+
 template <int GT, int NSPLIT>
 __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,               // [M][256] bf16: init block output in, tower output out
                                                           uint16_t* H,               // [M][256] bf16 scratch (conv1 outputs)
@@ -434,10 +464,12 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                                                           uint32_t* err, unsigned long long* dbg,
                                                           const BgState* __restrict__ states,    // non-null: the init block runs in here
                                                           const u32x4* __restrict__ winit,   // [8][9][64] x 16 B (k_conv3x3<16,...>'s fragments)
-                                                          const float* __restrict__ binit) { // [256]
+                                                          const float* __restrict__ binit,   // [256]
+                                                          ClusterHeads hd) {                 // whead non-null: head convs + policy FC in here
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
+    constexpr int LATE = KS == PF ? DIEE_CL_LATE : 0;   // of them, requested after the MFMA loop (see there); K split 4 ways: the ring covers half a layer, all inside
     constexpr int PRS = kClusterPartStride;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 35 + 15) / 16 * 16;
     constexpr int PART = NSPLIT * MF * 32 * PRS;
@@ -554,15 +586,23 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
 #else
 #define CL_STAMP(i) do {} while (0);
 #endif
-    for (int l = 0; l < 38; ++l) {
+    const bool heads = hd.whead != nullptr;
+    const int n_layers = heads ? (nslice < 2 ? 39 : 38) : 38;       // "layer 38": the head convs, on the workgroups of slices 0 and 1
+    // tag of layer 37's output when the heads consume it in here: bit 31 of the tagged words (the second element's sign
+    // bit) instead of bit 15 -- X must END the launch with bit 15 clear in every word, because the next launch's layer 1
+    // announces itself through bit 15 = 1 over whatever this one left; bit 31 is set by nobody else, layer 35's data
+    // (in place before layer 37's) has it clear, and every layer's store rewrites the whole word
+    constexpr uint32_t tag38 = 0x80000000u;
+    for (int l = 0; l < n_layers; ++l) {
         const __amdgpu_buffer_rsrc_t in = (l & 1) ? rH : rX, out = (l & 1) ? rX : rH;
         CL_STAMP(5)                                 // end-of-layer barrier
         float4 bias_lo[CH], bias_hi[CH];            // requested ahead of the epilogue
+        const float* bl = l < 38 ? bias + l * 256 + nslice * 32 : hd.bhead + nslice * 32;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int i = (tid + c * NT) < ROWS * 4 ? tid + c * NT : 0;
-            bias_lo[c] = *(const float4*)(bias + l * 256 + nslice * 32 + (i & 3) * 8);
-            bias_hi[c] = *(const float4*)(bias + l * 256 + nslice * 32 + (i & 3) * 8 + 4);
+            bias_lo[c] = *(const float4*)(bl + (i & 3) * 8);
+            bias_hi[c] = *(const float4*)(bl + (i & 3) * 8 + 4);
         }
         if (l == 1) {
             // ---- first hand-over (H holds unknown leftovers): meet on the group's counter ----
@@ -576,10 +616,56 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             __syncthreads();                        // the tile loads below are device-coherent themselves
         }
         // ---- stage the activation tile; from layer 2 on the data is its own ready flag (see tag_of) ----
+        // DIEE_CL_PRIVATE: every wave stages exactly the channel columns its own K share reads (wave w <-> input channels
+        // [w * 256 / NSPLIT, ...): with K split 8 ways those are the 32 channels ONE producer workgroup wrote), so nothing
+        // a wave reads in the MFMA loop was written by another wave: no workgroup barrier between staging and the loop, and a
+        // wave starts as soon as ITS producer's slice has landed instead of when the slowest of the eight has.
+#if DIEE_CL_PRIVATE
+        constexpr int CW = CPR / NSPLIT;                        // 16-byte chunks of a row inside this wave's columns (4 or 8)
+        constexpr int RPI = 64 / CW;                            // rows per wave-instruction (16 or 8)
+        const int crow = lane / CW, ccol = wave * CW + lane % CW;
+        if (l > 0 || !states) {
+            constexpr int NCH = (ROWS + RPI - 1) / RPI;         // chunks per lane
+            constexpr int BATCH = NCH > 8 ? 8 : NCH;            // requested back to back before the first is stored
+            const uint32_t tmask = l == 38 ? tag38 : 0x8000u;                 // where the producer's tag sits
+            const uint32_t want = l == 38 ? tag38 : l >= 2 ? tag_of(l - 1) : 0u;
+#pragma unroll
+            for (int k0 = 0; k0 < NCH; k0 += BATCH) {
+                u32x4 v[BATCH];
+                for (int spins = 0;; ++spins) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        const int r = crow + (k0 + k) * RPI;
+                        const int gr = row0 + ((k0 + k < NCH && r < ROWS) ? r : 0);      // ragged: re-read row 0, never stored
+                        v[k] = ld_coherent16(in, (gr < M ? gr : M - 1) * 512 + ccol * 16);
+                    }
+                    uint32_t bad = 0u;
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
+                    if ((bad & tmask) == 0u || l < 2 || dead) break;
+                    if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
+                    __builtin_amdgcn_s_sleep(DIEE_CL_POLL_SLEEP);
+                }
+                if (k0 == 0) CL_STAMP(0)            // first batch of the tile polled in
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int r = crow + (k0 + k) * RPI;
+                    if (row0 + r >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
+                    v[k][0] &= ~tmask; v[k][2] &= ~tmask;
+                    if (k0 + k < NCH && r < ROWS) *(u32x4*)(smem + r * RS + ccol * 16) = v[k];
+                }
+            }
+        }
+        // zero row, this wave's columns (the partial tiles may alias it: every layer)
+        if (lane < CW) *(u32x4*)(smem + ROWS * RS + (wave * CW + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+        if (wave == NSPLIT - 1 && lane >= 61) *(u32x4*)(smem + ROWS * RS + (CPR + lane - 61) * 16) = u32x4{0u, 0u, 0u, 0u};
+        __builtin_amdgcn_wave_barrier();            // (LDS operations of one wave execute in order: its reads below see these writes)
+#else
         if (l > 0 || !states) {
             constexpr int NCH = (ROWS * CPR + NT - 1) / NT;     // 16-byte chunks per thread
             constexpr int BATCH = NCH > 8 ? 8 : NCH;            // requested back to back before the first is stored
-            const uint32_t want = l >= 2 ? tag_of(l - 1) : 0u;
+            const uint32_t tmask = l == 38 ? tag38 : 0x8000u;                 // where the producer's tag sits
+            const uint32_t want = l == 38 ? tag38 : l >= 2 ? tag_of(l - 1) : 0u;
 #pragma unroll
             for (int k0 = 0; k0 < NCH; k0 += BATCH) {
                 u32x4 v[BATCH];
@@ -594,7 +680,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                     uint32_t bad = 0u;
 #pragma unroll
                     for (int k = 0; k < BATCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
-                    if ((bad & 0x8000u) == 0u || l < 2 || dead) break;
+                    if ((bad & tmask) == 0u || l < 2 || dead) break;
                     if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
                     __builtin_amdgcn_s_sleep(DIEE_CL_POLL_SLEEP);
                 }
@@ -603,7 +689,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                 for (int k = 0; k < BATCH; ++k) {
                     const int i = tid + (k0 + k) * NT;
                     if (row0 + i / CPR >= M) v[k] = u32x4{0u, 0u, 0u, 0u};
-                    v[k][0] &= ~0x8000u; v[k][2] &= ~0x8000u;
+                    v[k][0] &= ~tmask; v[k][2] &= ~tmask;
                     if ((ROWS * CPR % NT == 0 && NCH % BATCH == 0) || i < ROWS * CPR)
                         *(u32x4*)(smem + (i / CPR) * RS + (tid % CPR) * 16) = v[k];
                 }
@@ -611,6 +697,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         }
         if (tid < CPR + 3) *(u32x4*)(smem + ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};      // zero row
         __syncthreads();
+#endif
         CL_STAMP(1)                                 // tile staged (barrier)
 
         f32x16 acc[MF];
@@ -631,9 +718,11 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
 #if DIEE_TOWER_ABLATE == 4
         const u32x4* wn = wp + (size_t)(l & 1) * kTowerLayerStride;                  // timing experiment: weights stay L2-resident (wrong results)
 #else
-        const u32x4* wn = wp + (size_t)(l < 37 ? l + 1 : l) * kTowerLayerStride;     // next layer's fragments (last layer: reloads its own, unused)
+        // next layer's fragments (the head convs' after layer 37 where this workgroup runs them; last layer: reloads its own, unused)
+        const u32x4* whp = heads ? hd.whead + ((size_t)(nslice < 2 ? nslice : 0) * 144 + wave * KS) * 64 + lane : wp;
+        const u32x4* wn = l < 37 ? wp + (size_t)(l + 1) * kTowerLayerStride : (heads && nslice < 2) ? whp : wp + (size_t)37 * kTowerLayerStride;
 #endif
-        const u32x4* wc = wp + (size_t)l * kTowerLayerStride;                        // this layer's
+        const u32x4* wc = l < 38 ? wp + (size_t)l * kTowerLayerStride : whp;         // this layer's
 #pragma unroll
         for (int u = 0; u < (DIEE_CL_ABLATE == 1 ? 0 : KS); ++u) {
             const int un = u + PD;
@@ -642,7 +731,12 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                 for (int f = 0; f < MF; ++f) a[un % NB][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
             }
             const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
-            if (DIEE_CL_ABLATE != 3) bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];   // the ring runs ahead into the next layer
+            // the ring runs ahead into the next layer.  A CU takes in weights at ~64 B/clk: a layer's 147 KB need ~2300 cycles of
+            // that pipe, the MFMA loop lasts ~1400 -- with every request inside the loop the waves queue at the pipe and the
+            // loop stretches to the stream's length (in-kernel stamps: loop + wait for the slowest wave 3100 cycles of a 6100-cycle
+            // layer).  The last LATE fragments per wave (needed last in the next loop) are requested after the loop instead,
+            // while two of the eight waves reduce the partial tiles and store: that part of the layer uses no memory pipe.
+            if (DIEE_CL_ABLATE != 3 && (KS != PF || u < KS - LATE)) bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NB][f], b, acc[f], 0, 0, 0);
@@ -661,6 +755,11 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         if (DIEE_CL_ABLATE == 2) { float sink = 0.0f; for (int f = 0; f < MF; ++f) for (int i = 0; i < 16; ++i) sink += acc[f][i]; if (sink == 12345.678f) part[0] = 1; }
         __syncthreads();
         CL_STAMP(3)                                 // partial tiles written (barrier)
+        const bool has_out = wave * 64 < ROWS * 4;  // this wave reduces and stores output chunks (wave-uniform)
+        if (LATE > 0 && !has_out && DIEE_CL_ABLATE != 3) {
+#pragma unroll
+            for (int u = KS - LATE; u < KS; ++u) bq[u % PF] = wn[(u + PF - KS) * 64];
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int i = tid + c * NT, er = i >> 2, ec8 = i & 3, egr = row0 + er;
@@ -686,9 +785,26 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                 o[k] = (uint32_t)f2bf(x0) | ((uint32_t)f2bf(x1) << 16);
             }
             if (l & 1) resreg[c] = o;               // block output = next block's input
-            const uint32_t tg = l < 37 ? tag_of(l) : 0u;             // the tower output itself leaves untagged
+            if (l == 38) {
+                // heads (MODE 2 of k_conv3x3_sk): slice 0 = policy features, handed to the whole cluster through channels
+                // 0..31 of the H rows; slice 1 = value features (3 channels) -> hv, f32
+                if (nslice == 0) {
+                    o[0] |= tag_of(38); o[2] |= tag_of(38);
+                    st_coherent16(rH, (egr * 256 + ec8 * 8) * 2, o);
+                } else if (ec8 == 0) {
+                    float* ov = hd.hv + (size_t)(egr / 24) * 72 + (egr % 24) * 3;
+                    ov[0] = v[0] > 0.0f ? v[0] : 0.0f; ov[1] = v[1] > 0.0f ? v[1] : 0.0f; ov[2] = v[2] > 0.0f ? v[2] : 0.0f;
+                }
+                continue;
+            }
+            // the tower output leaves untagged when nothing in here reads it, else tagged in bit 31 (see tag38)
+            const uint32_t tg = l < 37 ? tag_of(l) : heads ? tag38 : 0u;
             o[0] |= tg; o[2] |= tg;
             st_coherent16(out, (egr * 256 + nslice * 32 + ec8 * 8) * 2, o);
+        }
+        if (LATE > 0 && has_out && DIEE_CL_ABLATE != 3) {      // behind this wave's stores: they are what the other workgroups wait for
+#pragma unroll
+            for (int u = KS - LATE; u < KS; ++u) bq[u % PF] = wn[(u + PF - KS) * 64];
         }
         CL_STAMP(4)                                 // reduce + store issued
         if (l == 0 || l == 37) {
@@ -705,6 +821,62 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             // pays: it keeps the waves that have no output chunk from polling the next tile (and loading the memory
             // system) while the others reduce and store
             __syncthreads();
+        }
+    }
+    if (heads) {
+        // ---- policy FC 768 -> 1352 over the cluster's boards: slices nslice, nslice + 8, ... of the 43, one wave each ----
+        char* hpt = smem;                               // [GT][kFcRowStride] policy features (the activation tile is done with)
+        const int s_first = nslice + 8 * wave;
+        constexpr int FB = 12;                          // weight fragments requested at a time (48 per slice)
+        u32x4 fb[FB];                                   // the first FB of the first slice: in flight during the poll
+        {
+            const u32x4* wf = hd.wfc + (size_t)(s_first < 43 ? s_first : 0) * 48 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < FB; ++i) fb[i] = wf[i * 64];
+        }
+        constexpr int NHC = (ROWS * 4 + NT - 1) / NT;   // 16-byte chunks of the features per thread (a row = 32 channels = 4 chunks)
+#pragma unroll
+        for (int c = 0; c < NHC; ++c) {
+            const int i = tid + c * NT, row = (i < ROWS * 4 ? i : 0) >> 2, ch = i & 3, gr = row0 + row;
+            u32x4 v;
+            for (int spins = 0;; ++spins) {
+                v = ld_coherent16(rH, (gr < M ? gr : M - 1) * 512 + ch * 16);
+                if ((((v[0] ^ tag_of(38)) | (v[2] ^ tag_of(38))) & 0x8000u) == 0u || dead) break;
+                if (spins > kClusterSpinLimit / 16) { atomicOr(err, 4u); dead = true; break; }
+                __builtin_amdgcn_s_sleep(DIEE_CL_POLL_SLEEP);
+            }
+            v[0] &= ~0x8000u; v[2] &= ~0x8000u;
+            if (gr >= M) v = u32x4{0u, 0u, 0u, 0u};
+            if (i < ROWS * 4) *(u32x4*)(hpt + (row / 24) * kFcRowStride + (row % 24) * 64 + ch * 16) = v;
+        }
+        __syncthreads();
+        for (int sl = s_first; sl < 43; sl += 8 * NSPLIT) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            const u32x4* wfs = hd.wfc + (size_t)sl * 48 * 64 + lane;
+            const char* ap = hpt + ((lane & 31) < GT ? (lane & 31) : 0) * kFcRowStride + (lane >> 5) * 16;     // rows past the cluster's boards: computed, never stored
+#pragma unroll
+            for (int part = 0; part < 48 / FB; ++part) {
+                if (part > 0 || sl != s_first) {
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) fb[i] = wfs[(part * FB + i) * 64];
+                }
+                // k_policy_fc's sequence: one accumulator, k-steps in order (same bits as the stand-alone FC)
+#pragma unroll
+                for (int i = 0; i < FB; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + (part * FB + i) * 32), __builtin_bit_cast(bf16x8, fb[i]), acc, 0, 0, 0);
+            }
+            const int n = sl * 32 + (lane & 31);
+            if (n < 1352) {
+                const float bv = hd.bfc[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const int g = grp * GT + r;
+                    if (r < GT && g * 24 < M) hd.logits[(size_t)g * 1352 + n] = acc[i] + bv;
+                }
+            }
         }
     }
 #if DIEE_TOWER_ABLATE == 3
@@ -1342,7 +1514,7 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 // runs the per-layer path)
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
-                            uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
+                            uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
@@ -1364,16 +1536,19 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
         return false;
     }
     hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid), dim3(64 * NSPLIT), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg,
-                       (const BgState*)states, (const u32x4*)winit, binit);
+                       (const BgState*)states, (const u32x4*)winit, binit, hd);
     return true;
 }
+// whead != nullptr: the launch also runs the head convs and the policy FC (hv / logits are written; X holds no output then)
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
-                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit) {
+                          int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
+                          const void* whead, const float* bhead, const void* wfc, const float* bfc, float* hv, float* logits) {
+    const ClusterHeads hd{(const u32x4*)whead, bhead, (const u32x4*)wfc, bfc, hv, logits};
     switch (boards_per_group) {
-        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);
-        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit);     // K split over 4 waves (one per SIMD)
+        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
+        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
+        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
+        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }
@@ -1499,7 +1674,9 @@ void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, con
     else if (mode == 1) conv256_dispatch<1>(st, act, wpack, bias, res, out, out_v, G, N);
     else if (mode == 3) conv256_dispatch<3>(st, act, wpack, bias, res, out, out_v, G, N);   // raw conv + bias (training)
     else if (G > 96) conv_sk_launch<2, 4>(st, act, wpack, bias, res, out, G, N, out_v);  // heads: N = 64 (35 real), split-K
-    else conv_sk_launch<2, 2>(st, act, wpack, bias, res, out, G, N, out_v);
+    else if (G > 72) conv_sk_launch<2, 2>(st, act, wpack, bias, res, out, G, N, out_v);
+    else conv_sk_launch<2, 2, 8>(st, act, wpack, bias, res, out, G, N, out_v);           // K over 8 waves, like the tower layers of this size
+                                                                                          // (and like the cluster tower's own head convs: same bits)
 }
 
 // ---- training-step helpers (die-e_amd/train_ops.py): the tower convolutions of the learn loop's training step run on the

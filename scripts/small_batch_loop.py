@@ -1,7 +1,7 @@
 """MCTS on a handful of roots (the self-play tail): per-iteration latency; run under rocprofv3 --kernel-trace --stats."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diee_amd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -89,11 +89,18 @@ def test_fused_bn_relu_matches_pytorch_batch_norm():
         assert all(e < 1e-2 for e in errs)
         # the pass also leaves the column sums of the dx it wrote (the bias gradient of the convolution in front): equal to
         # summing the bf16 dx afterwards, up to the fp32 summation order
-        ptr, colsum = ops._dx_colsum
-        assert ptr == outs[0].data_ptr()
+        colsum = ops._take_colsum(outs[0])                         # the hand-over a convolution backward would make (consumes the entry)
+        assert colsum is not None and ops._dx_colsum["dx"] is None
         want = outs[0].double().sum(0)
         assert float((colsum.double() - want).abs().max()) <= 1e-4 * float(outs[0].double().abs().sum(0).max()) + 1e-6
-        ops._dx_colsum[0] = ops._dx_colsum[1] = None
+        # a tensor that merely sits at some address, or the same tensor modified since, never matches
+        y2 = ops.BnReluTok.apply(x, gamma, beta, res, None, None, 0.1, 1e-5)
+        g2 = torch.autograd.grad(y2, x, dy)[0]
+        assert ops._take_colsum(torch.empty_like(g2)) is None and ops._dx_colsum["dx"] is None      # another tensor: no match, entry gone
+        y3 = ops.BnReluTok.apply(x, gamma, beta, res, None, None, 0.1, 1e-5)
+        g3 = torch.autograd.grad(y3, x, dy)[0]
+        g3.add_(1)
+        assert ops._take_colsum(g3) is None                        # written to since the pass summed it
 
 
 def test_one_launch_batch_norm_equals_the_three_launch_passes():
@@ -229,7 +236,7 @@ def test_bn_one_launch_passes_on_two_streams_and_the_runtime_switch():
     import importlib
     import torch
     ops = importlib.import_module("die-e_amd.train_ops")
-    L = diee_amd.load_library()
+    L = importlib.import_module("die-e_amd").load_library()
     torch.manual_seed(5)
     M = 6144
 
