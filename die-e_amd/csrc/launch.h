@@ -71,7 +71,10 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks);
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                   uint32_t next_it, float c);   // next_it: iteration to select for afterwards, kNoNextIteration = none
+                   uint32_t next_it, float c, bool pre_grown = false);   // next_it: iteration to select for afterwards, kNoNextIteration = none;
+                                                                         // pre_grown: launch_grow(it) created the children already
+// the network-independent half of expansion `it` (legal plays, child states): runs beside the network evaluation on another stream
+void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
 // rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
 // count also goes to rows_log[log_idx])

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "bg_device.h"
 #include "nn_device.h"
 #include "launch.h"
@@ -247,6 +249,11 @@ struct ExpandScratch {
     uint16_t code[kMaxPlays];
 };
 static_assert(sizeof(uint64_t) * 2 * kSeqCap >= sizeof(float) * 22 * 64, "the logits row fits over the dedup keys");
+// k_expand<true> (the children exist already, see k_grow): the logits row and the masked priors are all it stages
+struct SettleScratch {
+    float lgs[22 * 64];
+    float raw[kMaxPlays];
+};
 
 // turn_policy_to_probs_tensor (utils.rs:74-84; root: utils.rs:60-72 on the Dirichlet-mixed policy,
 // noise.rs:27-34) + alpha_expand_tensor (node.rs:157-174).  it == kRootIt expands the roots.
@@ -254,9 +261,12 @@ constexpr uint32_t kRootIt = 0xFFFFFFFFu;
 // After the expansion the same wave immediately selects this game's leaf for iteration `next_it` (kNoNext = none):
 // one MCTS kernel per network evaluation instead of two.
 constexpr uint32_t kNoNext = 0xFFFFFFFEu;
+// PRE: the children of the leaf were created by k_grow while the network ran (states, dice, parent, action code; priors open):
+// what is left for after the evaluation is what depends on it -- priors, the parent's link, backpropagation, the next descent.
+template <bool PRE>
 __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
                                                uint32_t next_it, float c) {
-    __shared__ ExpandScratch sc;
+    __shared__ typename std::conditional<PRE, SettleScratch, ExpandScratch>::type sc;
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
     EX_STAMP_INIT;
@@ -296,6 +306,10 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     const ValueHeadIn vh = value_head_load(S.hv + (size_t)row * 72, S.wv, lane);
     float lg[22];
     softmax_load(S.logits + (size_t)row * 1352, lane, lg);
+    // k_grow's hand-over: how many children it created for this slot (kNone: none -- nothing to expand, or no room) and
+    // their action codes, four per lane (child lane + 64 q in position q)
+    const uint32_t pre_k = PRE ? S.grow_k[slot] : kNone;
+    const uint2 pre_codes = PRE ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
     const bool active = if0 != 0;                           // alpha_mcts.rs:170-172 `continue`
     EX_STAMP(9);                                            // the first round of loads has landed
     if (active) {
@@ -327,6 +341,54 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
         if (lane == 0) S.root_value0[seg] = v0;
     }
     EX_STAMP(0);                                            // flags, value head, leaf meta
+    if constexpr (PRE) {
+    if (do_expand && !(m0 & kDrained) && pre_k != kNone) {
+        const int k = (int)pre_k;
+        float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
+        softmax_reduce(lg, lane, smM, smInv);
+#pragma unroll
+        for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
+        __syncthreads();
+        EX_STAMP(2);                                        // softmax constants
+        const float om = 1.0f - P.dir_eps;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            if (j < k) {
+                const uint32_t code = ((q & 2) ? pre_codes.y : pre_codes.x) >> (16 * (q & 1)) & 0xFFFFu;
+                float p = softmax_prob(sc.lgs[code], smM, smInv);
+                if (root) {                                  // apply_dirichlet: (1-eps)*P + eps*noise
+                    const float x = om * p, y = P.dir_eps * S.noise[(size_t)seg * 1352 + code];
+                    p = x + y;
+                }
+                sc.raw[j] = p;
+            }
+        }
+        __syncthreads();
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pr[r] = lane + 64 * r < k ? sc.raw[lane + 64 * r] : 0.0f;
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kr = k - 64 * r < 64 ? k - 64 * r : 64;                    // uniform
+            for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[r]), j));
+        }
+        EX_STAMP(3);                                        // priors + ordered row sum
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane + 64 * r < k) T.prior[base + first + lane + 64 * r] = pr[r] / sum;
+        const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+        if (lane == 0) {
+            T.first_child[base + node] = first;
+            T.meta[base + node] = nmeta;
+            T.used[slot] = first + (uint32_t)k;
+        }
+        if (node == 0) { rh.meta = nmeta; rh.first_child = first; }
+        cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
+        if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
+    }
+    } else {
     if (do_expand && !(m0 & kDrained)) {
         int k = bg_legal_plays_wave(st, &sc.ws, lane, S.overflow);
         if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }     // never silent: DIEE_ERR_CAPACITY
@@ -391,6 +453,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
         }
     }
+    }   // !PRE
     EX_STAMP(4);                                            // child creation (stores issued)
     __syncthreads();
     EX_STAMP(5);                                            // ... stores acknowledged
@@ -422,6 +485,63 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
 #ifdef DIEE_EXPAND_STAMPS
     if (threadIdx.x == 0) atomicAdd(&g_expand_stamps[15], 1ull);
 #endif
+}
+
+// ---- the part of an expansion that does not wait for the network --------------------------------------------------------
+// alpha_expand_tensor (node.rs:157-174) creates one child per legal play: state (apply_move with frozen dice), parent, action
+// code -- none of which depends on the evaluation of the leaf; only the priors do.  k_grow does that part for the leaf the
+// selection just chose, on a second stream WHILE the network evaluates it (one wave per slot; the tower leaves room for these
+// waves on every CU): legal plays, codes, child states and headers at [used, used + k) of the slot's arena -- not linked to
+// the parent and `used` not advanced, so the tree is unchanged until k_expand<true> commits them with their priors.
+// Slots::grow_k = k (kNone: nothing to expand here, or no room), Slots::grow_code = the codes, four per lane.
+__global__ __launch_bounds__(64) void k_grow(Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
+    __shared__ WaveScratch ws;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)slot * T.node_cap;
+    const bool root = it == kRootIt;
+    const uint32_t seg = G.n == 1 ? 0u : S.seg[slot];
+    const bool lterm = !root && S.leaf_term[slot] != 0;
+    const uint32_t leaf = root ? 0u : S.leaf[slot];
+    const uint32_t m0 = root ? T.meta[base] : S.leaf_meta[slot];
+    const uint32_t first = T.used[slot];
+    const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
+    const BgState st = load_state(root ? &T.state[base] : &S.eval_states[slot]);
+    const uint32_t if0 = root ? 1u : S.iter_flags[2 * ((size_t)seg * G.iter_cap + it)];
+    const unsigned long long seed = G.seed[seg];
+    if (if0 == 0 || lterm || (m0 & kDrained)) {             // k_expand's `active`, `do_expand` and drained tests
+        if (lane == 0) S.grow_k[slot] = kNone;
+        return;
+    }
+    int k = bg_legal_plays_wave(st, &ws, lane, S.overflow);
+    if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }     // never silent: DIEE_ERR_CAPACITY
+    if (first + (uint32_t)k > T.node_cap) {
+        if (lane == 0) { atomicOr(S.overflow, 2u); S.grow_k[slot] = kNone; }
+        return;
+    }
+    const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
+    const uint32_t e = root ? 0u : it + 1u;
+    uint32_t codes[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = lane + 64 * q;
+        if (j >= k) continue;
+        const uint32_t play = ws.play[j];
+        const uint32_t code = bg_encode_dev(r0, r1, play);
+        codes[q] = code;
+        if (root && bg_decode_dev(r0, r1, player, code) != play) atomicAdd(&S.slot_cnt[slot * SC_COUNT + SC_ILLEGAL], 1u);   // alpha_parallel.rs:204
+        const size_t ci = base + first + j;
+        BgState cs = st;
+        int d0, d1;
+        draw_dice(seed, gid, rnd, e, (uint32_t)j, d0, d1);          // child dice frozen at creation (Q9)
+        bg_apply_dev(cs, play, d0, d1);
+        store_state(&T.state[ci], cs);
+        T.visits[ci] = 0.0f; T.value[ci] = 0.0f;
+        T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = code;
+    }
+    *(uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) = make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
+    if (lane == 0) S.grow_k[slot] = (uint32_t)k;
 }
 
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
@@ -689,8 +809,12 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
     hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, G, n, it, c, quirks);
 }
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                   uint32_t next_it, float c) {
-    hipLaunchKernelGGL(k_expand, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+                   uint32_t next_it, float c, bool pre_grown) {
+    if (pre_grown) hipLaunchKernelGGL(k_expand<true>, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+    else hipLaunchKernelGGL(k_expand<false>, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+}
+void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
+    hipLaunchKernelGGL(k_grow, dim3(n), dim3(64), 0, st, T, S, G, n, it);
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

@@ -827,12 +827,13 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         // ---- policy FC 768 -> 1352 over the cluster's boards: slices nslice, nslice + 8, ... of the 43, one wave each ----
         char* hpt = smem;                               // [GT][kFcRowStride] policy features (the activation tile is done with)
         const int s_first = nslice + 8 * wave;
-        constexpr int FB = 12;                          // weight fragments requested at a time (48 per slice)
-        u32x4 fb[FB];                                   // the first FB of the first slice: in flight during the poll
+        // the whole first slice (48 fragments, 48 KB per wave) is requested before the poll: six of the eight workgroups wait
+        // out the head convolutions here anyway, and the tower's ring registers are dead by now
+        u32x4 fb[48];
         {
             const u32x4* wf = hd.wfc + (size_t)(s_first < 43 ? s_first : 0) * 48 * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < FB; ++i) fb[i] = wf[i * 64];
+            for (int i = 0; i < 48; ++i) fb[i] = wf[i * 64];
         }
         constexpr int NHC = (ROWS * 4 + NT - 1) / NT;   // 16-byte chunks of the features per thread (a row = 32 channels = 4 chunks)
 #pragma unroll
@@ -856,17 +857,14 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
             const u32x4* wfs = hd.wfc + (size_t)sl * 48 * 64 + lane;
             const char* ap = hpt + ((lane & 31) < GT ? (lane & 31) : 0) * kFcRowStride + (lane >> 5) * 16;     // rows past the cluster's boards: computed, never stored
+            if (sl != s_first) {                        // (K split 4 ways: a wave's second slice)
 #pragma unroll
-            for (int part = 0; part < 48 / FB; ++part) {
-                if (part > 0 || sl != s_first) {
-#pragma unroll
-                    for (int i = 0; i < FB; ++i) fb[i] = wfs[(part * FB + i) * 64];
-                }
-                // k_policy_fc's sequence: one accumulator, k-steps in order (same bits as the stand-alone FC)
-#pragma unroll
-                for (int i = 0; i < FB; ++i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + (part * FB + i) * 32), __builtin_bit_cast(bf16x8, fb[i]), acc, 0, 0, 0);
+                for (int i = 0; i < 48; ++i) fb[i] = wfs[i * 64];
             }
+            // k_policy_fc's sequence: one accumulator, k-steps in order (same bits as the stand-alone FC)
+#pragma unroll
+            for (int i = 0; i < 48; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(ap + i * 32), __builtin_bit_cast(bf16x8, fb[i]), acc, 0, 0, 0);
             const int n = sl * 32 + (lane & 31);
             if (n < 1352) {
                 const float bv = hd.bfc[n];

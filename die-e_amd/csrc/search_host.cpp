@@ -28,7 +28,10 @@ struct SearchBufs {
     DevBuf<uint32_t> game_id, round, seg, leaf, sel, iter_flags, row_slot, slot_row, n_rows;
     DevBuf<float> sel_value, noise, root_value0;
     DevBuf<uint8_t> leaf_term, path_len;
-    DevBuf<uint32_t> path, leaf_meta;
+    DevBuf<uint32_t> path, leaf_meta, grow_k;
+    DevBuf<uint16_t> grow_code;
+    hipStream_t side = nullptr;                                // k_grow runs here, beside the network on the engine's stream
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
     DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
@@ -48,6 +51,9 @@ struct SearchBufs {
     DevBuf<uint32_t> out_src;
     DevBuf<float> out_ps, out_planes;
     ~SearchBufs() {
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (ev_side) (void)hipEventDestroy(ev_side);
         if (noise_host) (void)hipHostFree(noise_host);
         if (live_host) (void)hipHostFree(live_host);
     }
@@ -116,6 +122,7 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.roots.ensure(sc); B.eval_states.ensure(sc); B.game_id.ensure(sc); B.round.ensure(sc); B.seg.ensure(sc);
         B.leaf.ensure(sc); B.sel.ensure(sc); B.sel_value.ensure(sc); B.leaf_term.ensure(sc);
         B.path.ensure((size_t)sc * kPathCap); B.path_len.ensure(sc); B.leaf_meta.ensure(sc);
+        B.grow_k.ensure(sc); B.grow_code.ensure((size_t)sc * kMaxPlays);
         B.row_slot.ensure(sc); B.slot_row.ensure(sc); B.n_rows.ensure(4);
         B.slot_cnt.ensure((size_t)sc * SC_COUNT);
         B.slot_cap = sc; B.node_cap = nc;
@@ -138,7 +145,7 @@ Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
                  nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p,
-                 B.leaf_meta.p, B.path.p, B.path_len.p, std::min<uint32_t>(env_u32("DIEE_PATH_CAP", kPathCap), kPathCap)};
+                 B.leaf_meta.p, B.path.p, B.path_len.p, B.grow_k.p, B.grow_code.p, std::min<uint32_t>(env_u32("DIEE_PATH_CAP", kPathCap), kPathCap)};
 }
 Segs segs_view(SearchBufs& B, uint32_t n_segs) {
     return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};
@@ -179,14 +186,36 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     HIPCHK(hipMemcpyAsync(B.noise.p, B.noise_host + (size_t)buf * kMaxSegments * 1352, sizeof(float) * 1352 * n_segs,
                           hipMemcpyHostToDevice, st));
     launch_init_roots(st, T, S, n);
+    // The network-independent half of every expansion (legal plays, child states: k_grow) runs on a second stream beside
+    // the evaluation of the leaf: main stream  select -> [network] -> k_expand<true>,  side stream  -> k_grow ->.
+    // Two events order them: k_grow(it) starts after the k_expand that selected its leaves, the k_expand that commits
+    // the children starts after k_grow(it).  DIEE_SPLIT_EXPAND=0: the one-kernel expansion of rounds 1-2.
+    static const bool split = env_u32("DIEE_SPLIT_EXPAND", 0) != 0;
+    if (split && !B.side) {
+        HIPCHK(hipStreamCreateWithFlags(&B.side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&B.ev_main, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&B.ev_side, hipEventDisableTiming));
+    }
+    auto grow = [&](uint32_t it) {
+        if (!split) return;
+        HIPCHK(hipEventRecord(B.ev_main, st));
+        HIPCHK(hipStreamWaitEvent(B.side, B.ev_main, 0));
+        launch_grow(B.side, T, S, G, n, it);
+        HIPCHK(hipEventRecord(B.ev_side, B.side));
+    };
+    auto join = [&] { if (split) HIPCHK(hipStreamWaitEvent(st, B.ev_side, 0)); };
+    grow(kRootIteration);
     nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr);        // forward_policy, alpha_mcts.rs:104 (softmax / tanh in k_expand)
     const SearchParams P{cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
-    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c);
+    join();
+    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, split);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
+        grow(it);
         const bool compacted = nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr, &rows);   // alpha_mcts.rs:186
         S.slot_row = compacted ? B.slot_row.p : nullptr;
-        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c);
+        join();
+        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, split);
     }
     launch_reduce_counters(st, S, G);
     HIPCHK(hipGetLastError());
