@@ -35,6 +35,10 @@ OK, ERR_ARG, ERR_HIP, ERR_NO_WEIGHTS, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
 BG_STATE = np.dtype([("pts", "i1", 24), ("bar", "u1", 2), ("off", "u1", 2), ("roll", "u1", 2),
                      ("player", "i1"), ("second", "u1")])
 assert BG_STATE.itemsize == 32
+# tic-tac-toe (BASELINE configs[0]): diee_ttt_state; an Engine(game_id=GAME_TTT) runs on the host (csrc/ttt_host.cpp)
+TTT_ACTIONS, TTT_PLANES = 9, 27
+TTT_STATE = np.dtype([("board", "i1", 9), ("player", "i1"), ("pad", "u1", 22)])
+assert TTT_STATE.itemsize == 32
 
 # every symbol include/diee.h declares (checked by the CPU test-suite against the built library); the development probes
 # of include/diee_dev.h are listed in DEV_EXPORTS
@@ -48,6 +52,7 @@ EXPORTS = [
     "diee_train_wgrad_scratch_floats", "diee_train_wgrad3x3",
     "diee_free_fragments", "diee_bg_legal_moves", "diee_bg_encode", "diee_bg_decode", "diee_bg_apply",
     "diee_bg_planes", "diee_det_pow",
+    "diee_ttt_valid_moves", "diee_ttt_apply_move", "diee_ttt_check_winner", "diee_ttt_planes",
 ]
 DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench", "diee_dev_wave_selftest"]
 
@@ -147,6 +152,10 @@ def load_library(path=None):
     L.diee_bg_apply.argtypes = [vp, vp, vp, vp, u32]; L.diee_bg_apply.restype = C.c_int
     L.diee_bg_planes.argtypes = [vp, vp, u32, vp]; L.diee_bg_planes.restype = C.c_int
     L.diee_det_pow.argtypes = [vp, vp, vp, u32, vp]; L.diee_det_pow.restype = C.c_int
+    L.diee_ttt_valid_moves.argtypes = [vp, vp]; L.diee_ttt_valid_moves.restype = u32
+    L.diee_ttt_apply_move.argtypes = [vp, C.c_uint8]; L.diee_ttt_apply_move.restype = None
+    L.diee_ttt_check_winner.argtypes = [vp, C.POINTER(C.c_int)]; L.diee_ttt_check_winner.restype = C.c_int
+    L.diee_ttt_planes.argtypes = [vp, vp]; L.diee_ttt_planes.restype = None
     L.diee_probe_f32.argtypes = [vp, vp, vp, u32, vp, vp, vp]; L.diee_probe_f32.restype = C.c_int
     L.diee_probe_dice.argtypes = [vp, u64, vp, u32, vp, vp]; L.diee_probe_dice.restype = C.c_int
     L.diee_dev_conv_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]; L.diee_dev_conv_bench.restype = C.c_int
@@ -184,7 +193,9 @@ class Engine:
     def __init__(self, device=0, game_id=GAME_BACKGAMMON):
         import sys
         self._L = load_library()
-        if _TORCH_LOADED_FIRST:             # torch's runtime serves the process: let it initialise before the engine does
+        self.game_id = game_id
+        self.n_actions, self.n_planes = (TTT_ACTIONS, TTT_PLANES) if game_id == GAME_TTT else (BG_ACTIONS, BG_PLANES)
+        if _TORCH_LOADED_FIRST and game_id != GAME_TTT:   # torch's runtime serves the process: let it initialise before the engine does
             sys.modules["torch"].cuda.is_available()
         h = C.c_void_p()
         st = self._L.diee_create(device, game_id, C.byref(h))
@@ -275,7 +286,7 @@ class Engine:
     def forward_t(self, states):
         """ResNet::forward_t (nnet.rs:120-133), eval mode -> (softmax policy [n,1352], tanh value [n])"""
         s = _states(states); n = len(s)
-        pol = np.zeros((n, BG_ACTIONS), dtype=np.float32); val = np.zeros(n, dtype=np.float32)
+        pol = np.zeros((n, self.n_actions), dtype=np.float32); val = np.zeros(n, dtype=np.float32)
         self._chk(self._L.diee_nn_forward(self._h, s.ctypes.data, n, pol.ctypes.data, val.ctypes.data))
         return pol, val
 
@@ -305,7 +316,7 @@ class Engine:
     def alpha_mcts_parallel(self, states, cfg, seed=0, step=0, game_ids=None, rounds=None, ref_quirks=True):
         """alpha_mcts_parallel + get_prob_tensor_parallel -> dict(probs [n,1352], n_children, root_visits, stats)"""
         s = _states(states); n = len(s)
-        probs = np.zeros((n, BG_ACTIONS), dtype=np.float32)
+        probs = np.zeros((n, self.n_actions), dtype=np.float32)
         nch = np.zeros(n, dtype=np.uint32); rv = np.zeros(n, dtype=np.float32)
         gi = None if game_ids is None else np.ascontiguousarray(game_ids, dtype=np.uint32)
         rd = None if rounds is None else np.ascontiguousarray(rounds, dtype=np.uint32)
@@ -320,10 +331,9 @@ class Engine:
     def _take_fragments(self, fr, out):
         n = fr.n
         out["outcome"] = np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8)
-        out["ps"] = (np.ctypeslib.as_array(fr.ps, shape=(n, BG_ACTIONS)).copy() if n
-                     else np.zeros((0, BG_ACTIONS), np.float32))
-        out["state"] = (np.ctypeslib.as_array(fr.state, shape=(n, BG_PLANES)).copy() if n
-                        else np.zeros((0, BG_PLANES), np.float32))
+        A, P = self.n_actions, self.n_planes
+        out["ps"] = np.ctypeslib.as_array(fr.ps, shape=(n, A)).copy() if n else np.zeros((0, A), np.float32)
+        out["state"] = np.ctypeslib.as_array(fr.state, shape=(n, P)).copy() if n else np.zeros((0, P), np.float32)
         out["game"] = np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
         self._L.diee_free_fragments(C.byref(fr))
 
@@ -356,3 +366,36 @@ class Engine:
                 self._take_fragments(frs[k], out)
             outs.append(out)
         return outs
+
+
+# ---- LearnableGame for TicTacToe (src/tictactoe/mod.rs), host functions of the C ABI -------------------------------------
+def ttt_new(n=None):
+    """TicTacToe::new (mod.rs:28-30): empty board, player -1 to move"""
+    s = np.zeros(() if n is None else n, dtype=TTT_STATE)
+    s["player"] = -1
+    return s
+
+
+def ttt_valid_moves(state):
+    mv = np.zeros(9, dtype=np.uint8)
+    k = load_library().diee_ttt_valid_moves(np.ascontiguousarray(state).ctypes.data, mv.ctypes.data)
+    return [int(x) for x in mv[:k]]
+
+
+def ttt_apply_move(state, move):
+    s = np.array(state, dtype=TTT_STATE, copy=True)
+    load_library().diee_ttt_apply_move(s.ctypes.data, int(move))
+    return s
+
+
+def ttt_check_winner(state):
+    """Some(winner) -> -1 / 0 (draw) / 1, None -> None"""
+    w = C.c_int(0)
+    over = load_library().diee_ttt_check_winner(np.ascontiguousarray(state).ctypes.data, C.byref(w))
+    return int(w.value) if over else None
+
+
+def ttt_planes(state):
+    out = np.zeros(TTT_PLANES, dtype=np.float32)
+    load_library().diee_ttt_planes(np.ascontiguousarray(state).ctypes.data, out.ctypes.data)
+    return out

@@ -21,7 +21,7 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch
 
-from . import BG_ACTIONS, BG_PLANES, ERR_ARG, ERR_HIP, DieeError, Engine, MctsConfig, random_weights
+from . import BG_ACTIONS, BG_PLANES, ERR_ARG, ERR_HIP, GAME_BACKGAMMON, GAME_TTT, DieeError, Engine, MctsConfig, random_weights
 from . import ot as _ot
 
 # PyTorch bundles its own HIP runtime; it has to initialise BEFORE libdiee.so's (system ROCm) runtime does,
@@ -81,12 +81,24 @@ class OptimizerParams:                                                          
         return cls(conf["wd"], conf["lr"])
 
 
+# --------------------------------------------------------------------------- the two games (base.rs:8-51 consts)
+class GameSpec:
+    """LearnableGame's associated constants + name(): backgammon_logic.rs:74-78,96-98 / tictactoe/mod.rs:18-34"""
+    def __init__(self, name, game_id, filters, blocks, actions, cin, h, w):
+        self.name, self.game_id, self.filters, self.blocks, self.actions, self.cin, self.h, self.w = name, game_id, filters, blocks, actions, cin, h, w
+        self.planes = cin * h * w
+
+
+BACKGAMMON = GameSpec("backgammon", GAME_BACKGAMMON, 256, 19, BG_ACTIONS, 6, 4, 6)
+TICTACTOE = GameSpec("tictactoe", GAME_TTT, 64, 4, 9, 3, 3, 3)
+
+
 # --------------------------------------------------------------------------- trainable ResNet (nnet.rs:24-34,57-155)
-def make_resnet():
+def make_resnet(spec=BACKGAMMON):
     import torch
     from torch import nn
 
-    F, BLOCKS, A = 256, 19, BG_ACTIONS
+    F, BLOCKS, A, HW = spec.filters, spec.blocks, spec.actions, spec.h * spec.w
 
     class ResBlock(nn.Module):                                                  # nnet.rs:16-46
         def __init__(self):
@@ -101,10 +113,10 @@ def make_resnet():
     class ResNet(nn.Module):
         def __init__(self):
             super().__init__()
-            self.init_conv = nn.Conv2d(6, F, 3, padding=1); self.init_bn = nn.BatchNorm2d(F)
+            self.init_conv = nn.Conv2d(spec.cin, F, 3, padding=1); self.init_bn = nn.BatchNorm2d(F)
             self.blocks = nn.ModuleList([ResBlock() for _ in range(BLOCKS)])
-            self.p_conv = nn.Conv2d(F, 32, 3, padding=1); self.p_bn = nn.BatchNorm2d(32); self.p_fc = nn.Linear(768, A)
-            self.v_conv = nn.Conv2d(F, 3, 3, padding=1); self.v_bn = nn.BatchNorm2d(3); self.v_fc = nn.Linear(72, 1)
+            self.p_conv = nn.Conv2d(F, 32, 3, padding=1); self.p_bn = nn.BatchNorm2d(32); self.p_fc = nn.Linear(32 * HW, A)
+            self.v_conv = nn.Conv2d(F, 3, 3, padding=1); self.v_bn = nn.BatchNorm2d(3); self.v_fc = nn.Linear(3 * HW, 1)
 
         engine_tower = False        # True: the 38 tower convolutions and their BatchNorm + ReLU run on the engine's own
                                     # kernels in the bf16 token layout (die-e_amd/train_ops.py); needs CUDA tensors
@@ -154,18 +166,20 @@ def make_resnet():
 # --------------------------------------------------------------------------- AlphaZero (alphazero.rs:61-67)
 class AlphaZero:
     def __init__(self, engine, config, mcts_config, op, blob=None, train_device=None, seed=0xD1EE0001,
-                 rank=0, world=1, root=".", quiet=False):
+                 rank=0, world=1, root=".", quiet=False, game=BACKGAMMON):
         import torch
         self.engine, self.config, self.mcts_config, self.op = engine, config, mcts_config, op
+        self.game = game                                            # handle_command::<T>, main.rs:119: the same driver for either game
+        self._in_shape = (game.cin, game.h, game.w)
         self.rank, self.world, self.root, self.quiet = rank, world, root, quiet
         self.seed = seed
         self.calls = 0
         self.shuffle_rng = np.random.default_rng(seed ^ 0x5EED)     # memory.shuffle(&mut thread_rng()) once per train() call, alphazero.rs:203-204
-        self.blob = np.ascontiguousarray(blob if blob is not None else random_weights(0), dtype=np.float32)
+        self.blob = np.ascontiguousarray(blob if blob is not None else random_weights(0, game.game_id), dtype=np.float32)
         if engine is not None:
             engine.load_weights(self.blob)
-        self.device = train_device or ("cuda" if TORCH_CUDA else "cpu")
-        self.model = make_resnet().load_blob(self.blob).to(self.device)
+        self.device = train_device or ("cuda" if TORCH_CUDA and game is BACKGAMMON else "cpu")   # tic-tac-toe: BASELINE configs[0], CPU
+        self.model = make_resnet(game).load_blob(self.blob).to(self.device)
         self.ddp = None
         if world > 1:
             from torch.nn.parallel import DistributedDataParallel as DDP
@@ -178,7 +192,7 @@ class AlphaZero:
                 self._set_bn_coop(False)
         on_gpu = torch.device(self.device).type == "cuda"
         # DIEE_TRAIN=torch: the all-PyTorch fp32 step (MIOpen convolutions); default on a GPU: the tower on the engine's kernels
-        self.model.engine_tower = on_gpu and os.environ.get("DIEE_TRAIN", "engine") != "torch"
+        self.model.engine_tower = on_gpu and game is BACKGAMMON and os.environ.get("DIEE_TRAIN", "engine") != "torch"
         # the whole step (forward, backward, Adam) replayed as one HIP graph for full batches (single-rank training only)
         self.use_graph = on_gpu and world == 1 and os.environ.get("DIEE_TRAIN_GRAPH", "1") != "0"
         self._graph = None
@@ -189,7 +203,7 @@ class AlphaZero:
     @classmethod
     def from_config(cls, engine, conf, model_path=None, **kw):                   # alphazero.rs:113-127, :81-100
         blob = None
-        mdir = os.path.join(kw.get("root", "."), "models", "backgammon")
+        mdir = os.path.join(kw.get("root", "."), "models", kw.get("game", BACKGAMMON).name)
         best = next((p for p in (os.path.join(mdir, "best_model.npy"), os.path.join(mdir, "best_model.ot")) if os.path.exists(p)), None)
         if model_path:
             blob = _ot.load_model(model_path)                                    # .npy blob or die-e's own .ot archive
@@ -223,7 +237,7 @@ class AlphaZero:
             batches.append((n, self.rank * n, self.seed + 0x9E3779B1 * self.calls))
         # a call takes at most 64 batches (kMaxSegments) and its fragment arena grows with the batches in flight
         # (games x (round_limit + 2) x 6 KB: 2.5 GB per 1024-game batch): groups within both limits, one call per group
-        per_batch = n * (self.mcts_config.round_limit + 2) * (BG_ACTIONS + BG_PLANES) * 4 + n * (self.mcts_config.iterations + 1) * 128 * 56
+        per_batch = n * (self.mcts_config.round_limit + 2) * (self.game.actions + self.game.planes) * 4 + n * (self.mcts_config.iterations + 1) * 128 * 56
         budget = int(float(os.environ.get("DIEE_PIPELINE_GB", "96")) * 2 ** 30)
         group = max(1, min(64, budget // max(per_batch, 1)))
         outs = []
@@ -248,7 +262,8 @@ class AlphaZero:
         if not os.path.isdir(path):
             raise FileNotFoundError(f"path: {path} does not exist!")
         fmt = fmt or os.environ.get("DIEE_DATA_FORMAT", "npy")
-        arrays = {"ps": memory["ps"], "states": memory["state"].reshape(-1, 6, 4, 6), "outcomes": memory["outcome"].astype(np.int8)}
+        shape = (3, 3, 3) if memory["state"].shape[-1] == 27 else (6, 4, 6)      # states [M,C,H,W] like Tensor::concat of as_tensor, alphazero.rs:160-170
+        arrays = {"ps": memory["ps"], "states": memory["state"].reshape(-1, *shape), "outcomes": memory["outcome"].astype(np.int8)}
         for stem, a in arrays.items():
             if fmt in ("npy", "both"):
                 np.save(os.path.join(path, stem + ".npy"), a)
@@ -263,16 +278,17 @@ class AlphaZero:
         def one(stem):
             npy = os.path.join(path, stem + ".npy")
             return np.load(npy) if os.path.exists(npy) else _ot.load_tensor_ot(os.path.join(path, stem + ".ot"))
-        return {"ps": one("ps").reshape(-1, BG_ACTIONS).astype(np.float32),
-                "state": one("states").reshape(-1, BG_PLANES).astype(np.float32),
-                "outcome": one("outcomes").reshape(-1).astype(np.int8)}
+        ps = one("ps")
+        ps = ps.reshape(-1, ps.shape[-1]).astype(np.float32)                     # [M, ACTION_SPACE_SIZE]
+        st = one("states")
+        return {"ps": ps, "state": st.reshape(len(ps), -1).astype(np.float32), "outcome": one("outcomes").reshape(-1).astype(np.int8)}
 
     @staticmethod
     def concat(mems):
         mems = [m for m in mems if len(m["outcome"])]
         if not mems:
             return {"outcome": np.zeros(0, np.int8), "ps": np.zeros((0, BG_ACTIONS), np.float32),
-                    "state": np.zeros((0, BG_PLANES), np.float32)}
+                    "state": np.zeros((0, BG_PLANES), np.float32)}            # (empty: the shapes carry no game)
         return {k: np.concatenate([m[k] for m in mems]) for k in ("outcome", "ps", "state")}
 
     # ---- train, alphazero.rs:202-261 ----
@@ -329,7 +345,7 @@ class AlphaZero:
         import torch
         if self._graph is not None and self._graph["bs"] == bs:
             return self._graph
-        g = {"bs": bs, "st": torch.zeros(bs, 6, 4, 6, device=self.device), "ps": torch.zeros(bs, BG_ACTIONS, device=self.device),
+        g = {"bs": bs, "st": torch.zeros(bs, *self._in_shape, device=self.device), "ps": torch.zeros(bs, self.game.actions, device=self.device),
              "oc": torch.zeros(bs, 1, device=self.device)}
         g["ps"][:, 0] = 1.0
         # warm-up and capture run real steps: parameters, BatchNorm statistics and Adam's moments are put back afterwards,
@@ -388,7 +404,7 @@ class AlphaZero:
                 cap = max(1 << 14, 1 << int(np.ceil(np.log2(n))))
                 self._mem = None
                 torch.cuda.empty_cache()
-                self._mem = {"st": torch.empty(cap, BG_PLANES, device=self.device), "ps": torch.empty(cap, BG_ACTIONS, device=self.device),
+                self._mem = {"st": torch.empty(cap, self.game.planes, device=self.device), "ps": torch.empty(cap, self.game.actions, device=self.device),
                              "oc": torch.empty(cap, device=self.device), "perm": torch.empty(cap, dtype=torch.int64, device=self.device),
                              "loss": torch.zeros(-(-cap // max(bs, 1)) + 1, device=self.device)}
                 self._mem_cap = cap
@@ -408,7 +424,7 @@ class AlphaZero:
         if use_graph:
             g = self._graphed_step(bs)
             i0 = perm_t[:bs]
-            if not self._graph_selfcheck(g, mem_st[i0].reshape(-1, 6, 4, 6), mem_ps[i0], mem_oc[i0].unsqueeze(1)):
+            if not self._graph_selfcheck(g, mem_st[i0].reshape(-1, *self._in_shape), mem_ps[i0], mem_oc[i0].unsqueeze(1)):
                 self.log("[train] the captured step does not reproduce the eager loss: training eagerly")
                 use_graph = False
         # The reference asserts on the loss BEFORE backward / step of every batch (alphazero.rs:248-255); here the losses are
@@ -421,10 +437,10 @@ class AlphaZero:
             for i, b0 in enumerate(range(0, n_steps * bs, bs)):                 # :205-206
                 if on_gpu:
                     idx = perm_t[b0:min(b0 + bs, n)]
-                    st = mem_st[idx].reshape(-1, 6, 4, 6); ps = mem_ps[idx]; oc = mem_oc[idx].unsqueeze(1)
+                    st = mem_st[idx].reshape(-1, *self._in_shape); ps = mem_ps[idx]; oc = mem_oc[idx].unsqueeze(1)
                 else:
                     idx = perm[b0:b0 + bs]
-                    st = torch.from_numpy(memory["state"][idx]).reshape(-1, 6, 4, 6)
+                    st = torch.from_numpy(memory["state"][idx]).reshape(-1, *self._in_shape)
                     ps = torch.from_numpy(memory["ps"][idx]); oc = torch.from_numpy(memory["outcome"][idx].astype(np.float32)).unsqueeze(1)
                 if use_graph and len(idx) == bs:
                     g["st"].copy_(st); g["ps"].copy_(ps); g["oc"].copy_(oc)
@@ -486,7 +502,7 @@ class AlphaZero:
     # ---- learn_parallel, alpha_parallel.rs:17-99 ----
     def learn_parallel(self, arena=True, arena_games=400, pipelined=True):
         run_id = secrets.token_urlsafe(16)[:21]                                 # nanoid!()
-        base = os.path.join(self.root, "data", "backgammon", f"run-{run_id}")
+        base = os.path.join(self.root, "data", self.game.name, f"run-{run_id}")
         if self.rank == 0:
             os.makedirs(base, exist_ok=True)
         self.log(f"Staring up run with run_id: {run_id}")
@@ -495,7 +511,8 @@ class AlphaZero:
             lrn = os.path.join(base, f"lrn-{l_i}")
             memory = []
             t_sp = time.time()
-            played = self.self_play_iterations_pipelined() if pipelined and hasattr(self.engine, "self_play_multi") else None
+            played = (self.self_play_iterations_pipelined() if pipelined and self.game is BACKGAMMON and hasattr(self.engine, "self_play_multi")
+                      else None)                                        # (the tic-tac-toe host path plays its batches one after the other)
             for sp_i in range(self.config.self_play_iterations):                # :49
                 memory.append(played[sp_i] if played is not None else self.self_play_parallel())
                 if self.rank == 0:
@@ -511,7 +528,7 @@ class AlphaZero:
             self.sync_engine()
             t_tr = time.time() - t_tr
             if self.rank == 0:
-                mdir = os.path.join(self.root, "models", "backgammon")
+                mdir = os.path.join(self.root, "models", self.game.name)
                 os.makedirs(mdir, exist_ok=True)
                 np.save(os.path.join(mdir, f"model_{l_i}.npy"), self.blob)      # :85-95
                 self.log(f"Iteration {l_i} saved successfully; {len(mem['outcome'])} fragments, self-play {t_sp:.1f} s, "
@@ -525,7 +542,9 @@ class AlphaZero:
     # ---- play_vs_best_model / play_vs_model, alpha_versus.rs:16-81 ----
     def play_vs_best_model(self, n_games=400):
         from .versus import Agent, Player, play
-        mdir = os.path.join(self.root, "models", "backgammon")
+        if self.game is TICTACTOE:
+            from .versus import play_tictactoe as play
+        mdir = os.path.join(self.root, "models", self.game.name)
         best = os.path.join(mdir, "best_model.npy")
         if not os.path.exists(best) and os.path.exists(os.path.join(mdir, "best_model.ot")):
             np.save(best, _ot.load_model_ot(os.path.join(mdir, "best_model.ot")))   # a die-e checkpoint brought along
@@ -534,7 +553,7 @@ class AlphaZero:
             os.makedirs(mdir, exist_ok=True)
             np.save(best, self.blob)
             return "saved-as-best"
-        other = Engine(self.engine.device)
+        other = Engine(self.engine.device, self.game.game_id)
         other.load_weights(np.load(best))
         res = play(Player(Agent.MODEL, self.engine), Player(Agent.MODEL, other), self.mcts_config,
                    self.config.temperature, seed=self.seed + 77 * self.calls, num_games=n_games)

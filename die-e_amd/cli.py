@@ -67,11 +67,48 @@ def get_all_paths_rec(d, res):
     return res
 
 
+def main_tictactoe(args):
+    """handle_command::<TicTacToe> (main.rs:112-114,119-216): the same driver on the tic-tac-toe host engine (BASELINE
+    configs[0]: CPU path, no GPU): learn, train and play; nothing here touches the HIP engine"""
+    from . import GAME_TTT, Engine
+    from .alphazero import TICTACTOE, AlphaZero, load_config, mcts_config_from
+    from .versus import Agent, Player, play_tictactoe
+    from .ot import load_model
+    if args.command == "replay":
+        sys.exit("replay prints backgammon boards (versus.rs:75-105 over Game<Backgammon> files)")
+    conf = load_config(args.config)
+    eng = Engine(0, GAME_TTT)
+    if args.command == "learn":
+        az = AlphaZero.from_config(eng, conf, model_path=args.model_path, game=TICTACTOE, train_device="cpu")
+        for row in az.learn_parallel():
+            print(row)
+    elif args.command == "train":
+        data_path = training_data_path("tictactoe", args.run_id, args.learn, args.self_play)
+        if not os.path.exists(data_path):
+            sys.exit(f"[TRAIN] the specified path {data_path} does not exist!")
+        mem = AlphaZero.concat([AlphaZero.load_training_data(p) for p in get_all_paths_rec(data_path, [])])
+        print(f"Total memory fragments: {len(mem['outcome'])}")
+        az = AlphaZero.from_config(eng, conf, model_path=args.model_path, game=TICTACTOE, train_device="cpu")
+        az.train(mem); az.sync_engine()
+        out = args.out_path or os.path.join(".", "models", "tictactoe", "trained_model.npy")
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+        np.save(out, az.blob)
+        print(f"Trained model saved successfully, saved to {out}")
+    elif args.command == "play":
+        def model(path):
+            if path is None:
+                return None
+            e = Engine(0, GAME_TTT); e.load_weights(load_model(path)); return e
+        a1, a2 = Agent.parse(args.agent_one), Agent.parse(args.agent_two)
+        print(play_tictactoe(Player(a1, model(args.model_path_one)), Player(a2, model(args.model_path_two)), mcts_config_from(conf),
+                             float(conf["temperature"])))
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.game != "backgammon":
-        sys.exit("tic-tac-toe runs on the CPU oracle only (BASELINE config 1 is CPU plumbing); "
-                 "the HIP engine implements backgammon")
+        return main_tictactoe(args)
     from . import Engine
     from .alphazero import AlphaZero, load_config, mcts_config_from
     from .versus import Agent, EngineRules, Player, play, print_game, save_game

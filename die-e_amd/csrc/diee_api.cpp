@@ -4,6 +4,7 @@
 #include "engine.h"
 #include "nn_host.h"
 #include "launch.h"
+#include "ttt_host.h"
 
 #include <mutex>
 #include <cstdarg>
@@ -38,9 +39,19 @@ using namespace diee;
     }                                                                       \
     return DIEE_OK;
 
-struct diee_ctx : public Engine {
-    using Engine::Engine;
+// a backgammon ctx is the HIP engine; a tic-tac-toe ctx (BASELINE configs[0], host path) carries its host engine instead
+// and answers DIEE_ERR_UNSUPPORTED wherever a HIP kernel would be needed
+struct diee_ctx {
+    char err[512];
+    int game;
+    Engine* hip = nullptr;
+    ttt::Engine* ttt = nullptr;
+    ~diee_ctx() { delete hip; delete ttt; }
 };
+static Engine* bg(diee_ctx* c) {
+    if (!c->hip) throw EngineError(DIEE_ERR_UNSUPPORTED, "this entry point needs a backgammon ctx (the tic-tac-toe ctx runs on the host)");
+    return c->hip;
+}
 
 extern "C" {
 
@@ -49,12 +60,18 @@ const char* diee_version(void) { return "die-e_amd 0.1 (gfx950)"; }
 diee_status diee_create(int device, int game_id, diee_ctx** out) {
     if (!out) return DIEE_ERR_ARG;
     *out = nullptr;
-    if (game_id != DIEE_GAME_BACKGAMMON) return DIEE_ERR_UNSUPPORTED;   // ttt is oracle-only
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DIEE_ERR_HIP;
+    if (game_id != DIEE_GAME_BACKGAMMON && game_id != DIEE_GAME_TTT) return DIEE_ERR_UNSUPPORTED;
     diee_ctx* c = nullptr;
     try {
-        c = new diee_ctx(device);
+        c = new diee_ctx();
+        c->err[0] = 0; c->game = game_id;
+        if (game_id == DIEE_GAME_TTT) {
+            c->ttt = new ttt::Engine();                 // BASELINE configs[0]: host path, no GPU involved (`device` is not looked at)
+        } else {
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { delete c; return DIEE_ERR_HIP; }
+            c->hip = new Engine(device);
+        }
     } catch (...) {
         delete c;
         return DIEE_ERR_HIP;
@@ -71,54 +88,54 @@ diee_status diee_bg_legal_moves(diee_ctx* c, const diee_bg_state* s, uint32_t n,
                                 uint32_t* counts) {
     API_BEGIN(c)
     if (!s || !plays || !counts) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->legal_moves(s, n, plays, cap, counts);
+    bg(c)->legal_moves(s, n, plays, cap, counts);
     API_END(c)
 }
 
 diee_status diee_bg_encode(diee_ctx* c, const diee_bg_state* s, const int8_t* plays, uint32_t n, uint32_t* codes) {
     API_BEGIN(c)
     if (!s || !plays || !codes) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->encode(s, plays, n, codes);
+    bg(c)->encode(s, plays, n, codes);
     API_END(c)
 }
 
 diee_status diee_bg_decode(diee_ctx* c, const diee_bg_state* s, const uint32_t* codes, uint32_t n, int8_t* plays) {
     API_BEGIN(c)
     if (!s || !plays || !codes) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->decode(s, codes, n, plays);
+    bg(c)->decode(s, codes, n, plays);
     API_END(c)
 }
 
 diee_status diee_bg_apply(diee_ctx* c, diee_bg_state* s, const int8_t* plays, const uint8_t* dice, uint32_t n) {
     API_BEGIN(c)
     if (!s || !plays || !dice) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->apply(s, plays, dice, n);
+    bg(c)->apply(s, plays, dice, n);
     API_END(c)
 }
 
 diee_status diee_bg_planes(diee_ctx* c, const diee_bg_state* s, uint32_t n, float* out) {
     API_BEGIN(c)
     if (!s || !out) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->planes(s, n, out);
+    bg(c)->planes(s, n, out);
     API_END(c)
 }
 
 diee_status diee_det_pow(diee_ctx* c, const float* x, const float* y, uint32_t n, float* out) {
     API_BEGIN(c)
     if (!x || !y || !out) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->probe_f32(x, y, n, nullptr, nullptr, out);
+    bg(c)->probe_f32(x, y, n, nullptr, nullptr, out);
     API_END(c)
 }
 
 diee_status diee_probe_f32(diee_ctx* c, const float* a, const float* b, uint32_t n, float* sq, float* dv, float* pw) {
     API_BEGIN(c)
-    c->probe_f32(a, b, n, sq, dv, pw);
+    bg(c)->probe_f32(a, b, n, sq, dv, pw);
     API_END(c)
 }
 
 diee_status diee_probe_dice(diee_ctx* c, uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni) {
     API_BEGIN(c)
-    c->probe_dice(seed, ctr, n, dice, uni);
+    bg(c)->probe_dice(seed, ctr, n, dice, uni);
     API_END(c)
 }
 
@@ -132,9 +149,26 @@ void random_weights_bg(uint64_t seed, float* blob);
 
 extern "C" {
 
-size_t diee_weights_count(int game_id) { return game_id == DIEE_GAME_BACKGAMMON ? diee::weights_count_bg() : 0; }
+size_t diee_weights_count(int game_id) {
+    return game_id == DIEE_GAME_BACKGAMMON ? diee::weights_count_bg() : game_id == DIEE_GAME_TTT ? diee::ttt::weights_count() : 0;
+}
+
+uint32_t diee_ttt_valid_moves(const diee_ttt_state* s, uint8_t* moves) { return (s && moves) ? (uint32_t)diee::ttt::valid_moves(*s, moves) : 0u; }
+void diee_ttt_apply_move(diee_ttt_state* s, uint8_t move) { if (s && move < 9) diee::ttt::apply_move(*s, move); }
+int diee_ttt_check_winner(const diee_ttt_state* s, int* winner) {
+    int w = 0;
+    const bool over = s && diee::ttt::check_winner(*s, w);
+    if (winner) *winner = w;
+    return over ? 1 : 0;
+}
+void diee_ttt_planes(const diee_ttt_state* s, float* out) { if (s && out) diee::ttt::planes(*s, out); }
 
 diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t n) {
+    if (game_id == DIEE_GAME_TTT) {
+        if (!blob || n != diee::ttt::weights_count()) return DIEE_ERR_ARG;
+        diee::ttt::random_weights(seed, blob);
+        return DIEE_OK;
+    }
     if (game_id != DIEE_GAME_BACKGAMMON) return DIEE_ERR_UNSUPPORTED;
     if (!blob || n != diee::weights_count_bg()) return DIEE_ERR_ARG;
     diee::random_weights_bg(seed, blob);
@@ -144,21 +178,23 @@ diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t 
 diee_status diee_load_weights(diee_ctx* c, const float* blob, size_t n) {
     API_BEGIN(c)
     if (!blob) throw EngineError(DIEE_ERR_ARG, "null blob");
-    c->load_weights(blob, n);
+    if (c->ttt) c->ttt->load_weights(blob, n);
+    else bg(c)->load_weights(blob, n);
     API_END(c)
 }
 
 diee_status diee_set_invariant_nn(diee_ctx* c, int on) {
     API_BEGIN(c)
-    if (!c->net) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
-    c->net->invariant = on != 0;
+    if (!bg(c)->net) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
+    bg(c)->net->invariant = on != 0;
     API_END(c)
 }
 
 diee_status diee_nn_forward(diee_ctx* c, const diee_bg_state* states, uint32_t n, float* policy, float* value) {
     API_BEGIN(c)
     if (!states || !policy || !value) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->nn_forward_host(states, n, policy, value);
+    if (c->ttt) c->ttt->forward((const diee_ttt_state*)states, n, policy, value);
+    else bg(c)->nn_forward_host(states, n, policy, value);
     API_END(c)
 }
 
@@ -168,7 +204,8 @@ diee_status diee_mcts_batch(diee_ctx* c, const diee_bg_state* roots, uint32_t n,
                             diee_stats* stats) {
     API_BEGIN(c)
     if (!roots || !cfg || !visit_probs) throw EngineError(DIEE_ERR_ARG, "null pointer");
-    c->mcts_batch(roots, n, cfg, seed, step, game_ids, rounds, flags, visit_probs, n_children, root_visits, stats);
+    if (c->ttt) c->ttt->mcts_batch((const diee_ttt_state*)roots, n, *cfg, seed, step, game_ids, rounds, flags, visit_probs, n_children, root_visits, stats);
+    else bg(c)->mcts_batch(roots, n, cfg, seed, step, game_ids, rounds, flags, visit_probs, n_children, root_visits, stats);
     API_END(c)
 }
 
@@ -177,7 +214,8 @@ diee_status diee_self_play(diee_ctx* c, uint32_t n_games, uint32_t first_game_id
                            diee_fragments* out, diee_stats* stats) {
     API_BEGIN(c)
     if (!cfg || n_games == 0) throw EngineError(DIEE_ERR_ARG, "bad arguments");
-    c->self_play(n_games, first_game_id, cfg, temperature, seed, flags, max_steps, out, stats);
+    if (c->ttt) c->ttt->self_play(n_games, first_game_id, *cfg, temperature, seed, flags, max_steps, out, stats);
+    else bg(c)->self_play(n_games, first_game_id, cfg, temperature, seed, flags, max_steps, out, stats);
     API_END(c)
 }
 
@@ -186,15 +224,15 @@ diee_status diee_self_play_multi(diee_ctx* c, const diee_batch* batches, uint32_
                                  diee_stats* stats) {
     API_BEGIN(c)
     if (!cfg || !batches) throw EngineError(DIEE_ERR_ARG, "bad arguments");
-    c->self_play_multi(batches, n_batches, cfg, temperature, flags, max_steps, outs, stats);
+    bg(c)->self_play_multi(batches, n_batches, cfg, temperature, flags, max_steps, outs, stats);
     API_END(c)
 }
 
 diee_status diee_dev_conv_bench(diee_ctx* c, int G, int variant, int reps, float* us_mode0, float* us_mode1,
                                 float* us_forward) {
     API_BEGIN(c)
-    HIPCHK(hipSetDevice(c->device));
-    nn_conv_bench(*c, G, variant, reps, us_mode0, us_mode1, us_forward);
+    HIPCHK(hipSetDevice(bg(c)->device));
+    nn_conv_bench(*bg(c), G, variant, reps, us_mode0, us_mode1, us_forward);
     API_END(c)
 }
 
@@ -202,19 +240,20 @@ diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint3
                                  float* mean_plays) {
     API_BEGIN(c)
     if (!states || !n || reps <= 0 || !us_legal_moves || !mean_plays) throw EngineError(DIEE_ERR_ARG, "bad arguments");
-    c->rules_bench(states, n, reps, us_legal_moves, mean_plays);
+    bg(c)->rules_bench(states, n, reps, us_legal_moves, mean_plays);
     API_END(c)
 }
 
 diee_status diee_dev_wave_selftest(diee_ctx* c, uint32_t salt, uint32_t* mismatches) {
     API_BEGIN(c)
     if (!mismatches) throw EngineError(DIEE_ERR_ARG, "bad arguments");
-    HIPCHK(hipSetDevice(c->device));
-    c->tmp_c.ensure(4);
-    HIPCHK(hipMemsetAsync(c->tmp_c.p, 0, 4, c->stream));
-    launch_wave_selftest(c->stream, (uint32_t*)c->tmp_c.p, salt);
-    c->d2h((uint8_t*)mismatches, c->tmp_c.p, 4);
-    c->sync();
+    Engine* e = bg(c);
+    HIPCHK(hipSetDevice(e->device));
+    e->tmp_c.ensure(4);
+    HIPCHK(hipMemsetAsync(e->tmp_c.p, 0, 4, e->stream));
+    launch_wave_selftest(e->stream, (uint32_t*)e->tmp_c.p, salt);
+    e->d2h((uint8_t*)mismatches, e->tmp_c.p, 4);
+    e->sync();
     API_END(c)
 }
 

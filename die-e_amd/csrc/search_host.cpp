@@ -89,7 +89,8 @@ struct DirRng {
     }
 };
 
-void dirichlet_host(uint64_t seed, uint32_t step, float alpha, int n, float* out) {
+}  // namespace
+void dirichlet_host(uint64_t seed, uint32_t step, float alpha, int n, float* out) {      // (also drawn by ttt_host.cpp)
     DirRng r{seed, step, 0};
     const double a = (double)alpha;
     std::vector<double> g((size_t)n);
@@ -102,6 +103,7 @@ void dirichlet_host(uint64_t seed, uint32_t step, float alpha, int n, float* out
     }
     for (int i = 0; i < n; ++i) out[i] = (float)(g[(size_t)i] / sum);
 }
+namespace {
 
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = getenv(name);

@@ -281,3 +281,77 @@ def play(player1, player2, mcts_config, temp, seed=0xD1EE0001, num_games=400, ro
     res.final_states = states
     res.rounds = round_count
     return res
+
+
+# ---- the same arena for tic-tac-toe (play::<TicTacToe>, versus.rs:160-268 is generic over LearnableGame) ------------------
+def play_tictactoe(player1, player2, mcts_config, temp, seed=0xD1EE0001, num_games=400, round_limit=400):
+    """Model / Random agents on the tic-tac-toe host engine (BASELINE configs[0]); player1 plays side -1 in every game, the
+    second half of the games starts after a skip_turn() (:172-174), a draw (check_winner = Some(0)) has no winner"""
+    from . import TTT_ACTIONS, ttt_apply_move, ttt_check_winner, ttt_new, ttt_valid_moves
+    states = ttt_new(num_games)
+    states["player"][num_games // 2:] = 1
+    alive = np.ones(num_games, dtype=bool)
+    wins_p1 = wins_p2 = 0
+    round_count = 0
+    rules_eng = player1.model or player2.model
+    while alive.any():
+        live = np.nonzero(alive)[0]
+        sides = (live[states["player"][live] == -1], live[states["player"][live] != -1])
+        acts = {}
+        for side, (pl, ids) in enumerate(((player1, sides[0]), (player2, sides[1]))):
+            if len(ids) == 0:
+                continue
+            # the sampling uniforms: the engine's Philox stream (seed, game, round, TAG_SAMPLE); tic-tac-toe has no dice
+            uni = np.array([_uniform01(seed, int(g), round_count) for g in ids])
+            if pl.player_type == Agent.MODEL:
+                r = pl.model.alpha_mcts_parallel(states[ids], mcts_config, seed, 2 * round_count + side, ids.astype(np.uint32),
+                                                 np.full(len(ids), round_count, dtype=np.uint32), ref_quirks=True)
+                inv_t = np.float32(1.0 / float(temp))
+                for k, g in enumerate(ids):
+                    if r["n_children"][k] == 0:
+                        continue                                                      # EMPTY_MOVE, versus.rs:292
+                    row = np.nan_to_num(r["probs"][k]).astype(np.float32)
+                    nz = row > 0
+                    powed = np.zeros(TTT_ACTIONS, dtype=np.float32)
+                    powed[nz] = np.power(row[nz].astype(np.float64), float(inv_t)).astype(np.float32)   # .pow_(1.0 / temp), :283
+                    acts[int(g)] = weighted_select(powed, float(uni[k]))
+            elif pl.player_type == Agent.RANDOM:
+                for k, g in enumerate(ids):
+                    vm = ttt_valid_moves(states[g])
+                    if vm:
+                        acts[int(g)] = vm[min(int(uni[k] * len(vm)), len(vm) - 1)]
+            else:
+                raise NotImplementedError("Agent::Mcts (vanilla MCTS with rollouts) is out of scope: SURVEY section 2 row 11")
+        round_count += 1                                                                 # :219
+        for g in np.concatenate(sides):
+            g = int(g)
+            if g not in acts:                                                            # :225-228 skip_turn; continue
+                states[g]["player"] = -states[g]["player"]
+                continue
+            assert acts[g] in ttt_valid_moves(states[g]), "decoded action is not a valid move"       # :229
+            states[g] = ttt_apply_move(states[g], acts[g])
+            w = ttt_check_winner(states[g])
+            if w is None and round_count >= round_limit:
+                w = 0                                                                    # :235
+            if w is None:
+                continue
+            alive[g] = False
+            wins_p1 += w == -1; wins_p2 += w == 1
+    res = PlayResult(player1.player_type, player2.player_type, int(wins_p1), int(wins_p2), num_games, [])
+    res.final_states = states
+    res.rounds = round_count
+    return res
+
+
+def _uniform01(seed, game, rnd):
+    """draw_uniform of csrc/bg_device.h (Philox4x32-10 keyed by seed / game / round / TAG_SAMPLE) on the host, for the arena's
+    sampling of a game without an engine-side draw entry point"""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = [game & 0xFFFFFFFF, rnd & 0xFFFFFFFF, TAG_SAMPLE, 0]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    x = (c[3] << 32) | c[2]
+    return (x >> 11) * (1.0 / 9007199254740992.0)

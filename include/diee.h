@@ -33,8 +33,10 @@ extern "C" {
 #define DIEE_BG_ACTIONS 1352u   /* Backgammon::ACTION_SPACE_SIZE, backgammon_logic.rs:74 */
 #define DIEE_BG_PLANES  144u    /* 6 x 4 x 6,  backgammon_logic.rs:75-76,198-252         */
 #define DIEE_NO_MOVE    (-2)    /* filler for the unused (from,to) slots of a play         */
-#define DIEE_GAME_TTT        0  /* tic-tac-toe: oracle/CPU plumbing only, no HIP kernels   */
+#define DIEE_GAME_TTT        0  /* tic-tac-toe: BASELINE configs[0], host path (see below)  */
 #define DIEE_GAME_BACKGAMMON 1
+#define DIEE_TTT_ACTIONS 9u     /* TicTacToe::ACTION_SPACE_SIZE, src/tictactoe/mod.rs:20     */
+#define DIEE_TTT_PLANES  27u    /* 3 x 3 x 3, mod.rs:83-94                                   */
 
 typedef enum {
     DIEE_OK = 0,
@@ -56,6 +58,19 @@ typedef struct {
     int8_t  player;
     uint8_t second;            /* is_second_play                                          */
 } diee_bg_state;
+
+/* TicTacToe{player, board}, src/tictactoe/mod.rs:5-12 (id dropped), padded to the 32-byte state record the
+ * batched entry points take.  BASELINE.json configs[0] names this game as "CPU reference path (plumbing, no GPU)":
+ * a ctx created with DIEE_GAME_TTT runs rules, the 64-filter 4-block ResNet (mod.rs:20-24), the search and the
+ * self-play driver in C++ on the HOST (die-e_amd/csrc/ttt_host.cpp) and needs no GPU; its states are diee_ttt_state
+ * records (cast the pointer where a prototype says diee_bg_state), policies / ps rows have 9 entries, planes 27.
+ * Served for such a ctx: diee_load_weights, diee_nn_forward, diee_mcts_batch, diee_self_play (+ lifetime / error calls);
+ * everything else answers DIEE_ERR_UNSUPPORTED.  The backgammon ctx has no host path. */
+typedef struct {
+    int8_t  board[9];          /* 0 | 1 | 2 / 3 | 4 | 5 / 6 | 7 | 8; -1 / 0 / +1            */
+    int8_t  player;            /* -1 moves first, mod.rs:28-30                              */
+    uint8_t pad[22];
+} diee_ttt_state;
 
 /* MctsConfig, src/lib.rs:33-40 (keys: iterations, exploration_const, simulate_round_limit,
  * dirichlet_alpha, dirichlet_epsilon; config-example.toml:11-15) */
@@ -131,7 +146,7 @@ const char* diee_version(void);
  *   policy: conv.w[32][256][3][3] conv.b[32] bn.{g,b,m,v}[32] fc.w[1352][768] fc.b[1352]
  *   value:  conv.w[3][256][3][3]  conv.b[3]  bn.{g,b,m,v}[3]  fc.w[1][72]     fc.b[1]
  * BatchNorm is folded (eval mode, eps 1e-5) and weights are packed to bf16 MFMA fragments. */
-size_t      diee_weights_count(int game_id);
+size_t      diee_weights_count(int game_id);       /* same layout for DIEE_GAME_TTT with 64 filters, 4 blocks, 3 input planes, 3x3 */
 /* tch-default random init (nnet.rs: kaiming-uniform conv/linear weights, conv bias 0, linear bias
  * U(+-1/sqrt(fan_in)), BN gamma U(0,1), beta 0, mean 0, var 1) from a counter-based generator */
 diee_status diee_random_weights(int game_id, uint64_t seed, float* blob, size_t n);
@@ -246,6 +261,12 @@ diee_status diee_bg_apply(diee_ctx*, diee_bg_state* s /* in/out */, const int8_t
                           const uint8_t* dice, uint32_t n);
 /* as_tensor, backgammon_logic.rs:198-252: out[n][144] */
 diee_status diee_bg_planes(diee_ctx*, const diee_bg_state* s, uint32_t n, float* out);
+/* ---- LearnableGame for TicTacToe (src/tictactoe/mod.rs:36-94), host functions, no ctx */
+uint32_t diee_ttt_valid_moves(const diee_ttt_state* s, uint8_t* moves /*[9]*/);     /* get_valid_moves :36-44 -> count */
+void     diee_ttt_apply_move(diee_ttt_state* s, uint8_t move);                       /* apply_move :46-49 */
+int      diee_ttt_check_winner(const diee_ttt_state* s, int* winner);               /* check_winner :60-81: 1 = Some(*winner) (0 = draw), 0 = None */
+void     diee_ttt_planes(const diee_ttt_state* s, float* out /*[27]*/);              /* as_tensor :83-94 */
+
 /* Tensor::pow_(1 / temperature) as the self-play and arena drivers apply it to the visit distribution
  * (alpha_parallel.rs:165, versus.rs:283): out[i] = x[i] ^ y[i] with the engine's deterministic powf (IEEE operations only,
  * <= 1 ulp from libm, the same bits on the host oracle and on the GPU) */

@@ -23,14 +23,15 @@ class BlobReader:
         return self.take(c), self.take(c), self.take(c), self.take(c)   # gamma, beta, mean, var
 
 
-def parse(blob):
+def parse(blob, filters=F, blocks=BLOCKS, actions=A, cin=6, hw=24):
+    """defaults: backgammon (backgammon_logic.rs:74-78); tic-tac-toe: filters=64, blocks=4, actions=9, cin=3, hw=9 (tictactoe/mod.rs:20-24)"""
     r = BlobReader(blob)
-    net = {"init": (r.conv(F, 6), r.bn(F)), "blocks": []}
-    for _ in range(BLOCKS):
-        c1 = r.conv(F, F); c2 = r.conv(F, F); b1 = r.bn(F); b2 = r.bn(F)
+    net = {"init": (r.conv(filters, cin), r.bn(filters)), "blocks": []}
+    for _ in range(blocks):
+        c1 = r.conv(filters, filters); c2 = r.conv(filters, filters); b1 = r.bn(filters); b2 = r.bn(filters)
         net["blocks"].append((c1, b1, c2, b2))
-    net["p"] = (r.conv(32, F), r.bn(32), r.take(A, 768), r.take(A))
-    net["v"] = (r.conv(3, F), r.bn(3), r.take(1, 72), r.take(1))
+    net["p"] = (r.conv(32, filters), r.bn(32), r.take(actions, 32 * hw), r.take(actions))
+    net["v"] = (r.conv(3, filters), r.bn(3), r.take(1, 3 * hw), r.take(1))
     assert r.o == len(r.b), (r.o, len(r.b))
     return net
 
@@ -41,9 +42,10 @@ def conv_bn(x, conv, bn):
 
 
 @torch.no_grad()
-def forward_t(net, planes, dtype=torch.float32):
-    """planes [n,144] (c*24+p) -> (softmax policy [n,1352], tanh value [n]); nnet.rs:120-133, train=false"""
-    x = torch.as_tensor(planes, dtype=torch.float32).reshape(-1, 6, 4, 6).to(dtype)
+def forward_t(net, planes, dtype=torch.float32, shape=(6, 4, 6)):
+    """planes [n,144] (c*24+p) -> (softmax policy [n,1352], tanh value [n]); nnet.rs:120-133, train=false
+    (shape = the game's input planes: (6, 4, 6) backgammon, (3, 3, 3) tic-tac-toe)"""
+    x = torch.as_tensor(planes, dtype=torch.float32).reshape(-1, *shape).to(dtype)
     cast = lambda t: tuple(cast(u) for u in t) if isinstance(t, tuple) else t.to(dtype)
     net = {k: cast(v) if k != "blocks" else [cast(b) for b in v] for k, v in net.items()}
     x = torch.relu(conv_bn(x, *net["init"]))

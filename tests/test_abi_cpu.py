@@ -102,7 +102,11 @@ def test_no_gpu_means_loud_failure_not_a_fallback():
     # unsupported game id / bad args are status codes, never aborts
     L = diee_amd.load_library()
     h = C.c_void_p()
-    assert L.diee_create(0, diee_amd.GAME_TTT, C.byref(h)) == diee_amd.ERR_UNSUPPORTED
+    assert L.diee_create(0, 7, C.byref(h)) == diee_amd.ERR_UNSUPPORTED           # no such game
+    # tic-tac-toe (BASELINE configs[0], "CPU reference path (plumbing, no GPU)") is a host path by definition of the config:
+    # its ctx needs no GPU (tests/test_ttt_cpu.py); the backgammon ctx -- the hot path -- has nothing of the kind
+    assert L.diee_create(0, diee_amd.GAME_TTT, C.byref(h)) == diee_amd.OK
+    L.diee_destroy(h)
     assert L.diee_create(0, 1, None) == diee_amd.ERR_ARG
     assert L.diee_load_weights(None, None, 0) == diee_amd.ERR_ARG
 
