@@ -222,6 +222,32 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
             }
         }
     }
+#ifndef DIEE_PAIR_DEDUP
+#define DIEE_PAIR_DEDUP 0      // measured: +0.9 us per k_expand launch against the hash table (profiles/r03i_*): off
+#endif
+    if (DIEE_PAIR_DEDUP && S <= 64) {
+        // At most one sequence per lane (the usual case: 30 at the opening, 12-13 plays on average): first-occurrence-wins
+        // dedup (:753-774) by comparing every lane's key with the keys of the lanes before it, broadcast one after the other
+        // through v_readlane -- no hash table, no LDS atomics, one barrier instead of three per round.  The 128-bit delta key
+        // has 77 significant bits (a: 12 x 3 + 5 bits of counters, b: 12 x 3): three dwords, compared exactly.
+        __syncthreads();
+        uint64_t ka = 0, kb = 0;
+        uint32_t mine = 0u;
+        if (lane < S) { ka = sc->keyA[lane]; kb = sc->keyB[lane]; mine = sc->play[lane]; }
+        const uint32_t w0 = (uint32_t)ka, w1 = (uint32_t)(ka >> 32) | ((uint32_t)kb << 9), w2 = (uint32_t)(kb >> 23);
+        bool dup = false;
+        for (int j = 0; j + 1 < S; ++j) {                            // uniform trip count
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, j), o1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, j),
+                           o2 = (uint32_t)__builtin_amdgcn_readlane((int)w2, j);
+            dup = dup || (j < lane && o0 == w0 && o1 == w1 && o2 == w2);
+        }
+        const bool keep = lane < S && !dup;
+        const unsigned long long bal = __ballot(keep);
+        __syncthreads();                                             // every lane holds its play: the list is rewritten in place
+        if (keep) sc->play[__popcll(bal & ((1ull << lane) - 1ull))] = mine;
+        __syncthreads();
+        return __popcll(bal);
+    }
     for (int i = lane; i < kTbl; i += 64) sc->owner[i] = kEmpty;
     for (int i = lane; i < S; i += 64) sc->status[i] = 0;
     __syncthreads();

@@ -75,6 +75,9 @@ void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
                                                                          // pre_grown: launch_grow(it) created the children already
 // the network-independent half of expansion `it` (legal plays, child states): runs beside the network evaluation on another stream
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
+// the policy FC over Gfc rows (n_rows non-null: a compacted batch) and launch_grow(it) in ONE launch
+void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc, const uint32_t* n_rows,
+                    const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
 // rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
 // count also goes to rows_log[log_idx])

@@ -106,8 +106,15 @@ __device__ __forceinline__ Best wave_best(Best b) {
 // cn: the slot's counters, held in registers by the caller (a read-modify-write of a counter in memory is a round trip the
 // wave waits out).  hdr: the root's header when the caller knows it (it just updated the root itself), else null.
 struct NodeHdr { uint32_t meta, first_child; float visits; };
+// The first level of the descent without a trip to memory: the root's children always sit at nodes 1 .. k of the slot's
+// arena (the root is expanded first), so the caller can request lane j's child (statistics, header, state) with its very
+// first burst of loads, long before the descent, and patch in what the kernel itself changed since (this selection's
+// backpropagation touches exactly one of them).  north_star: "UCB selection staged" -- in registers, one child per lane;
+// the levels below are reached through one round trip each.
+struct Level0 { float vis, val, pr; uint32_t cm, cf; BgState cs; bool valid; };
 __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t slot, uint32_t seg, int lane,
-                                            uint32_t it, float c, uint32_t quirks, uint32_t (&cn)[SC_COUNT], const NodeHdr* hdr) {
+                                            uint32_t it, float c, uint32_t quirks, uint32_t (&cn)[SC_COUNT], const NodeHdr* hdr,
+                                            const Level0* l0 = nullptr) {
     const size_t base = (size_t)slot * T.node_cap;
     uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);            // this batch's flags of iteration `it`
     uint32_t node = 0, depth = 0;
@@ -131,11 +138,16 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
 #pragma unroll
         for (int q = 0; q < 8; ++q) bs.w[q] = 0u;
         int lastnan = -1;
+        const bool staged = l0 && l0->valid && depth == 0 && k <= 64 && fc == 1;
         for (uint32_t j = lane; j < k; j += 64) {
             const size_t ci = base + fc + j;
-            const float vis = T.visits[ci], val = T.value[ci], pr = T.prior[ci];
-            const uint32_t cm = T.meta[ci], cf = T.first_child[ci];
-            const BgState cs = load_state(&T.state[ci]);    // rides the same round trip: the leaf's state needs none of its own
+            float vis, val, pr; uint32_t cm, cf; BgState cs;
+            if (staged) { vis = l0->vis; val = l0->val; pr = l0->pr; cm = l0->cm; cf = l0->cf; cs = l0->cs; }
+            else {
+                vis = T.visits[ci]; val = T.value[ci]; pr = T.prior[ci];
+                cm = T.meta[ci]; cf = T.first_child[ci];
+                cs = load_state(&T.state[ci]);              // rides the same round trip: the leaf's state needs none of its own
+            }
             const float q = vis == 0.0f ? 0.0f : val / vis;
             const float t = sq / (vis + 1.0f);
             const float u = c * t;
@@ -308,6 +320,20 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     softmax_load(S.logits + (size_t)row * 1352, lane, lg);
     // k_grow's hand-over: how many children it created for this slot (kNone: none -- nothing to expand, or no room) and
     // their action codes, four per lane (child lane + 64 q in position q)
+    // the root's children, one per lane, for the first level of the descent that follows (see Level0); patched below with
+    // what this kernel changes in them
+    Level0 l0;
+#ifndef DIEE_STAGE_L0
+#define DIEE_STAGE_L0 0        // measured: +0.2 us per launch (the seven extra loads per lane cost more than the round trip they save; profiles/r03i_*): off
+#endif
+    l0.valid = DIEE_STAGE_L0 && !root && next_it != kNoNext;
+    {
+        const size_t c0 = base + 1 + (l0.valid ? lane : 0);
+        l0.vis = T.visits[c0]; l0.val = T.value[c0]; l0.pr = T.prior[c0]; l0.cm = T.meta[c0]; l0.cf = T.first_child[c0];
+        l0.cs = load_state(&T.state[c0]);
+    }
+    // lane of the root child on the recorded path of this slot's selection (depth 1), -1: the path ends at the root
+    const int j1 = plen >= 2 ? __builtin_amdgcn_readlane((int)pnode, 1) - 1 : -1;
     const uint32_t pre_k = PRE ? S.grow_k[slot] : kNone;
     const uint2 pre_codes = PRE ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
     const bool active = if0 != 0;                           // alpha_mcts.rs:170-172 `continue`
@@ -327,8 +353,9 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             if (quirks) {
                 const uint32_t s = S.sel[slot];
                 if (s != kNone) {
-                    if (plen) backprop_path(T, base, pnode, lane, plen, S.sel_value[slot]);
-                    else if (lane == 0) backprop(T, base, s, S.sel_value[slot]);
+                    const float sv = S.sel_value[slot];
+                    if (plen) { backprop_path(T, base, pnode, lane, plen, sv); if (lane == j1) { l0.vis += 1.0f; l0.val += sv; } }
+                    else { if (lane == 0) backprop(T, base, s, sv); l0.valid = false; }      // (parent walk: which root child it passes is not recorded)
                     rh.visits += 1.0f;                      // the root is on every path
                 }
             }
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
             T.used[slot] = first + (uint32_t)k;
         }
         if (node == 0) { rh.meta = nmeta; rh.first_child = first; }
+        if (plen == 2 && lane == j1) { l0.cm = nmeta; l0.cf = first; }          // the expanded leaf is a root child: its staged header
         cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
         if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
     }
@@ -449,6 +477,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
                 T.used[slot] = first + (uint32_t)k;
             }
             if (node == 0) { rh.meta = nmeta; rh.first_child = first; }
+        if (plen == 2 && lane == j1) { l0.cm = nmeta; l0.cf = first; }          // the expanded leaf is a root child: its staged header
             cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
             if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
         }
@@ -458,8 +487,8 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     __syncthreads();
     EX_STAMP(5);                                            // ... stores acknowledged
     if (do_backprop) {
-        if (plen) backprop_path(T, base, pnode, lane, plen, v);
-        else if (lane == 0) backprop(T, base, node, v);
+        if (plen) { backprop_path(T, base, pnode, lane, plen, v); if (lane == j1) { l0.vis += 1.0f; l0.val += v; } }
+        else { if (lane == 0) backprop(T, base, node, v); l0.valid = false; }
         rh.visits += 1.0f;
     }
     if (!root && quirks && slot == seg_first && ifl.y != 0) {
@@ -478,7 +507,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     if (next_it != kNoNext) {
         __syncthreads();                                    // lane 0's tree updates are visible to the whole wave
         EX_STAMP(7);
-        select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh);
+        select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh, &l0);
         EX_STAMP(8);                                        // descent + leaf state + flags
     }
     if (lane == 0) store_counters(S, slot, cn);
@@ -494,9 +523,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
 // waves on every CU): legal plays, codes, child states and headers at [used, used + k) of the slot's arena -- not linked to
 // the parent and `used` not advanced, so the tree is unchanged until k_expand<true> commits them with their priors.
 // Slots::grow_k = k (kNone: nothing to expand here, or no room), Slots::grow_code = the codes, four per lane.
-__global__ __launch_bounds__(64) void k_grow(Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
-    __shared__ WaveScratch ws;
-    const uint32_t slot = blockIdx.x;
+__device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, uint32_t slot, WaveScratch& ws) {
     if (slot >= n) return;
     const int lane = threadIdx.x;
     const size_t base = (size_t)slot * T.node_cap;
@@ -542,6 +569,28 @@ __global__ __launch_bounds__(64) void k_grow(Tree T, Slots S, Segs G, uint32_t n
     }
     *(uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) = make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
     if (lane == 0) S.grow_k[slot] = (uint32_t)k;
+}
+__global__ __launch_bounds__(64) void k_grow(Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
+    __shared__ WaveScratch ws;
+    grow_slot(T, S, G, n, it, blockIdx.x, ws);
+}
+// The policy FC of an evaluation and the growth of the tree for the SAME iteration in one launch (batches above 256 boards,
+// where the FC is a launch of its own behind the fused tower): blocks [0, fc_blocks) are policy_fc_tile's (gx x 43 tiles),
+// the rest grow one slot each.  The two halves share nothing -- the FC reads the head features and writes logits, the
+// growth reads the selection and writes unlinked children -- so the 8 us of legal plays and child states disappear behind
+// the FC's 15 us instead of sitting in k_expand on the chain between two evaluations, with no cross-stream event.
+struct FcArgs { const uint16_t* hp; const void* wfc; const float* bfc; float* logits; int G; const uint32_t* n_rows; int gx; };
+__global__ __launch_bounds__(64) void k_fc_grow(FcArgs fc, Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
+    __shared__ WaveScratch ws;
+    const int fc_blocks = fc.gx * 43;
+    if ((int)blockIdx.x < fc_blocks) {
+        const int g0 = ((int)blockIdx.x % fc.gx) * 32, nslice = (int)blockIdx.x / fc.gx;
+        int Gr = fc.G;
+        if (fc.n_rows) { Gr = (int)*fc.n_rows; if (g0 >= Gr) return; }
+        policy_fc_tile(fc.hp, (const fc_u32x4*)fc.wfc, fc.bfc, fc.logits, Gr, g0, nslice, threadIdx.x);
+        return;
+    }
+    grow_slot(T, S, G, n, it, blockIdx.x - (uint32_t)fc_blocks, ws);
 }
 
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
@@ -815,6 +864,12 @@ void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 }
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
     hipLaunchKernelGGL(k_grow, dim3(n), dim3(64), 0, st, T, S, G, n, it);
+}
+void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc, const uint32_t* n_rows,
+                    const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
+    const int gx = (Gfc + 31) / 32;
+    const FcArgs fc{hp, wfc, bfc, logits, Gfc, n_rows, gx};
+    hipLaunchKernelGGL(k_fc_grow, dim3((unsigned)(gx * 43) + n), dim3(64), 0, st, fc, T, S, G, n, it);
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

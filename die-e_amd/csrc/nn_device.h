@@ -58,4 +58,49 @@ __device__ __forceinline__ float value_head(const float* __restrict__ hv_row, co
     return value_head_eval(value_head_load(hv_row, wv, lane), lane);
 }
 
+// ---- policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight from L2 (the layer is
+// ~0.2 % of the network's FLOPs).  A device function so that the search can run it inside a launch of its own that ALSO
+// grows the tree (mcts_kernels.hip, k_fc_grow); k_policy_fc is the stand-alone launch of the same code.
+typedef __attribute__((ext_vector_type(8))) __bf16 fc_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float fc_f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t fc_u32x4;
+__device__ __forceinline__ void policy_fc_tile(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
+                                               const fc_u32x4* __restrict__ wpack, // [43][48][64] x 16 B
+                                               const float* __restrict__ bias,     // [1376]
+                                               float* __restrict__ logits,         // [G][1352]
+                                               int G, int g0, int nslice, int lane) {
+    int row = g0 + (lane & 31);
+    const bool rok = row < G;
+    if (!rok) row = G - 1;
+    const uint16_t* ap = hp + (size_t)row * 768 + (lane >> 5) * 8;
+    const fc_u32x4* wp = wpack + (size_t)nslice * 48 * 64 + lane;
+    fc_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // the layer is latency-bound (48 dependent-free k-steps, operands straight from L2): request 24 k-steps of
+    // both operands up front, then issue their MFMAs, twice
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        fc_bf16x8 av[24];
+        fc_u32x4 bvq[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            av[i] = *(const fc_bf16x8*)(ap + (half * 24 + i) * 16);
+            bvq[i] = wp[(half * 24 + i) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep all 48 loads ahead of the first MFMA
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(fc_bf16x8, bvq[i]), acc, 0, 0, 0);
+    }
+    const int n = nslice * 32 + (lane & 31);
+    if (n >= 1352) return;
+    const float bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int g = g0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (g < G) logits[(size_t)g * 1352 + n] = acc[i] + bv;
+    }
+}
+
 }  // namespace diee

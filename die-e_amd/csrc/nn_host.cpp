@@ -384,6 +384,12 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     return fc_done;
 }
 
+static void fc_launch(Engine& e, const uint16_t* hp, float* logits, int G, const uint32_t* n_rows = nullptr) {
+    NetWeights& W = *e.net;
+    if (W.fc_hook) W.fc_hook->fn(W.fc_hook->ctx, e.stream, hp, W.wfc.p, W.bfc.p, logits, G, n_rows);
+    else launch_policy_fc(e.stream, hp, W.wfc.p, W.bfc.p, logits, G, n_rows);
+}
+
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
 // More boards than one pass of the chip holds (256 CUs x 4 boards): the whole multiples of kFullChip go through ONE
 // launch of the 4-board fused tower (its workgroups run in full rounds), the remainder through the fused geometry that is
@@ -417,7 +423,7 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
             HIPCHK(hipEventRecord(ev1, st));
             W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq});     // flops per ROW: the row count is in rows_log[seq]
         }
-        launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G, rows->n_rows);
+        fc_launch(e, W.hp.p, W.logits.p, G, rows->n_rows);
         HIPCHK(hipGetLastError());
         return true;
     }
@@ -430,9 +436,9 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     const bool fc_main = nn_conv_chunk(e, states_dev, 0, main_rows);
     const bool fc_rest = main_rows < G ? nn_conv_chunk(e, states_dev, main_rows, G - main_rows, true) : true;
     // the policy FC for the rows whose launch did not run it itself (the cluster tower does)
-    if (!fc_main && !fc_rest) launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, G);
-    else if (!fc_main) launch_policy_fc(st, W.hp.p, W.wfc.p, W.bfc.p, W.logits.p, main_rows);
-    else if (!fc_rest) launch_policy_fc(st, W.hp.p + (size_t)main_rows * 768, W.wfc.p, W.bfc.p, W.logits.p + (size_t)main_rows * 1352, G - main_rows);
+    if (!fc_main && !fc_rest) fc_launch(e, W.hp.p, W.logits.p, G);
+    else if (!fc_main) fc_launch(e, W.hp.p, W.logits.p, main_rows);
+    else if (!fc_rest) fc_launch(e, W.hp.p + (size_t)main_rows * 768, W.logits.p + (size_t)main_rows * 1352, G - main_rows);
     if (policy_dev) launch_softmax_value(st, W.logits.p, W.hv.p, W.wv.p, policy_dev, value_dev, G);
     HIPCHK(hipGetLastError());
     return false;

@@ -39,6 +39,11 @@ struct NetWeights {
                                     // it run whole multiples in one launch and the remainder in a launch of its own (0: never split)
     bool fused_heads = true;        // the fused tower runs the head convs itself (its output tile never leaves the CU)
     bool cluster_init = true;       // the cluster tower runs the init block itself (every workgroup, for its cluster's boards)
+    // the search's hook on the policy FC: when set, the FC launch of an evaluation goes out through it (so that the search can
+    // fuse the network-independent half of its expansion into the same launch, k_fc_grow); an evaluation may launch the FC
+    // once, twice (rows in two chunks) or not at all (the cluster tower runs it itself)
+    struct FcHook { void (*fn)(void* ctx, hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int G, const uint32_t* n_rows); void* ctx; };
+    const FcHook* fc_hook = nullptr;
     bool cluster_heads = true;      // ... and the head convs and the policy FC (an evaluation below 257 boards = cluster launch + k_expand)
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias

@@ -1410,48 +1410,15 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
     }
 }
 
-// policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight
-// from L2 (the layer is ~0.2 % of the network's FLOPs).
+// policy FC 768 -> 1352 (nnet.rs:80-85) as a launch of its own: policy_fc_tile (nn_device.h), one wave per 32 games x 32 outputs
 __global__ __launch_bounds__(64) void k_policy_fc(const uint16_t* __restrict__ hp,    // [G][768] bf16, k' = p*32+c
                                                   const u32x4* __restrict__ wpack,   // [43][48][64] x 16 B
                                                   const float* __restrict__ bias,    // [1376]
                                                   float* __restrict__ logits,        // [G][1352]
                                                   int G, const uint32_t* __restrict__ n_rows /* non-null: the rows of a compacted batch */) {
-    const int lane = threadIdx.x;
-    const int g0 = blockIdx.x * 32, nslice = blockIdx.y;
+    const int g0 = blockIdx.x * 32;
     if (n_rows) { G = (int)*n_rows; if (g0 >= G) return; }
-    int row = g0 + (lane & 31);
-    const bool rok = row < G;
-    if (!rok) row = G - 1;
-    const uint16_t* ap = hp + (size_t)row * 768 + (lane >> 5) * 8;
-    const u32x4* wp = wpack + (size_t)nslice * 48 * 64 + lane;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    // the layer is latency-bound (48 dependent-free k-steps, operands straight from L2): request 24 k-steps of
-    // both operands up front, then issue their MFMAs, twice
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        bf16x8 av[24];
-        u32x4 bvq[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            av[i] = *(const bf16x8*)(ap + (half * 24 + i) * 16);
-            bvq[i] = wp[(half * 24 + i) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);          // keep all 48 loads ahead of the first MFMA
-#pragma unroll
-        for (int i = 0; i < 24; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bvq[i]), acc, 0, 0, 0);
-    }
-    const int n = nslice * 32 + (lane & 31);
-    if (n >= 1352) return;
-    const float bv = bias[n];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int g = g0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        if (g < G) logits[(size_t)g * 1352 + n] = acc[i] + bv;
-    }
+    policy_fc_tile(hp, (const fc_u32x4*)wpack, bias, logits, G, g0, blockIdx.y, threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void k_softmax_value(const float* __restrict__ logits, const float* __restrict__ hv,
