@@ -148,6 +148,8 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
+    if (const char* v = getenv("DIEE_TOWER_PAIR")) net->pair_tower = atoi(v) != 0;
+    if (!net->pair_tower) net->tower_table = {{928, 8}, {416, 6}, {256, 3}};
     if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
@@ -246,6 +248,16 @@ void Engine::load_weights(const float* blob, size_t n) {
         sync();
     }
     W.loaded = true;
+}
+
+static uint16_t* pair_exchange(Engine& e) {
+    NetWeights& W = *e.net;
+    if (!W.pair_tower) return nullptr;
+    if (!W.pair_ex.p) {
+        W.pair_ex.ensure(tower_pair_exchange_bytes() / 2);
+        HIPCHK(hipMemsetAsync(W.pair_ex.p, 0, tower_pair_exchange_bytes(), e.stream));     // no tag set anywhere: the state every launch leaves behind
+    }
+    return W.pair_ex.p;
 }
 
 void nn_reserve(Engine& e, int G) {
@@ -349,6 +361,17 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (cluster(states_dev, W.cluster_heads)) { kind = 2; done = true; heads_done = fc_done = W.cluster_heads; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
+    if (!done && tgeom == 10) {
+        // 257 ... 512 boards: the fused tower on pairs of workgroups (init block and head convs inside)
+        stamp0();
+        if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards() &&
+            launch_tower_pair(st, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p, hp, hv, pair_exchange(e), e.flags_dev.p)) {
+            done = true; heads_done = true; W.cluster_used = true;    // (its hand-overs report through the same flag bit as the cluster tower's)
+        } else {
+            if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
+            tgeom = 3;
+        }
+    }
     if (!done && tgeom >= 0 && tower_geometry_has_init(tgeom) && W.cluster_init) {
         // large batches: init block + all 38 layers in one launch, activations stay in LDS
         stamp0();
@@ -417,8 +440,10 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         launch_row_map(st, rows->skip, (uint32_t)G, rows->row_slot, rows->slot_row, rows->n_rows, W.rows_log.p, seq);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (sample) { ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st)); }
+        uint16_t* pex = pair_exchange(e);
+        if (pex) W.cluster_used = true;
         launch_tower_compact(st, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
-                             W.hp.p, W.hv.p, rows->row_slot, rows->n_rows);
+                             W.hp.p, W.hv.p, rows->row_slot, rows->n_rows, pex, e.flags_dev.p);
         if (sample) {
             HIPCHK(hipEventRecord(ev1, st));
             W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq});     // flops per ROW: the row count is in rows_log[seq]
@@ -457,6 +482,7 @@ bool nn_cluster_used(Engine& e) {
 void nn_disable_cluster(Engine& e) {
     if (!e.net) return;
     e.net->cluster_table.clear();
+    e.net->pair_tower = false; e.net->tower_table = {{928, 8}, {416, 6}, {256, 3}};   // the pair tower hands over inside its launch too
     uint32_t f = 0;
     e.d2h(&f, e.flags_dev.p, 1);
     e.sync();
@@ -541,7 +567,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
     const auto saved_cl = W.cluster_table;
-    if (variant >= 100 && variant <= 109) W.tower_table = {{0, variant - 100}};
+    if (variant >= 100 && variant <= 110) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
     if (variant == 201 || variant == 202 || variant == 204 || variant == 208) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();

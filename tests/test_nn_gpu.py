@@ -351,3 +351,27 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     assert same_support == 1.0                  # legal plays are integer work: identical
     # measured (round 2): agreement 0.992, TV mean 0.0010, p95 0.0100, max 0.0183; bounds = 3 x measured
     assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.06
+
+
+def test_pair_tower_is_bit_identical_to_the_fused_geometries(oracle, monkeypatch):
+    """257 ... 512 boards run the fused tower on PAIRS of workgroups (k_tower16p: each member computes half the output
+    channels of every layer and hands them to the other through tagged write-through granules): per output element the
+    arithmetic is k_tower16's, K order included -- same bits as the 4-board and 2-board geometries, for full and ragged
+    groups, run after run (a hand-off that delivered stale bytes would show as a difference)"""
+    import diee_amd
+    blob = diee_amd.random_weights(0)
+    walk = oracle.random_walk_states(61, 14)
+    states = walk[np.linspace(0, len(walk) - 1, 512).astype(int)]
+    monkeypatch.setenv("DIEE_TOWER_PAIR", "0")
+    ref = diee_amd.Engine(0); ref.load_weights(blob)
+    monkeypatch.setenv("DIEE_TOWER_PAIR", "1")
+    pair = diee_amd.Engine(0); pair.load_weights(blob)
+    rng = np.random.default_rng(2)
+    for rep in range(40):
+        G = int(rng.integers(257, 513)) if rep >= 6 else (257, 258, 300, 301, 511, 512)[rep]
+        p0, v0 = ref.forward_t(states[:G])
+        p, v = pair.forward_t(states[:G])
+        assert (p == p0).all() and (v == v0).all(), (G, float(np.abs(p - p0).max()))
+    p1024 = ref.forward_t(np.concatenate([states, states]))[0]          # the 4-board one-pass kernel: the same bits again
+    assert (p1024[:512] == pair.forward_t(states)[0]).all()
+    ref.close(); pair.close()
