@@ -40,6 +40,12 @@
 #define DIEE_CL_LATE 6            // cluster tower: how many of a layer's 18 next-layer weight fragments per wave are requested AFTER the MFMA loop
                                   // (in the shadow of the partial-tile reduction) instead of inside it; 0 = all inside (rounds 1-2)
 #endif
+#ifndef DIEE_PAIR_STORE_AUX
+#define DIEE_PAIR_STORE_AUX 0     // pair tower hand-off stores: 0 = plain (the line stays in the XCD's L2, where the other member's sc1 loads find it:
+                                  // 327 ... 407 us), 16 = sc1 (write-through, placement-independent: 340 ... 414 us).  As in the cluster tower a pair that
+                                  // does NOT share an XCD never sees plain data: its polls time out, the engine reports it and falls back (tags per
+                                  // 8 bytes: nothing stale is ever taken)
+#endif
 #ifndef DIEE_PAIR_ABLATE
 #define DIEE_PAIR_ABLATE 0        // timing builds (wrong results): 1 = members do not wait for each other (one unchecked read), 2 = no exchange at all
 #endif
@@ -1428,8 +1434,8 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
 // border-aware rows: k_tower16<4, ...>'s arithmetic per output element, the K order included, so results are bit-identical to
 // the other fused geometries) and streams HALF the weights; after a layer each member hands its 96 x 128 outputs to the other
 // through global memory: 8-byte granules whose first element's sign bit is the ready tag (activations are post-ReLU), written
-// write-through (sc1) and polled with sc1 loads -- placement-independent, no fence, no counter (MI355X guide, data-tagged
-// granules).  The K loop runs the input channels in order, 0 ... 127 then 128 ... 255: member 0 owns the first half, so it
+// plain (both members sit on one XCD under round-robin dispatch and meet in its L2; see DIEE_PAIR_STORE_AUX) and polled with
+// L1-bypassing sc1 loads: no fence, no counter (MI355X guide, data-tagged granules).  The K loop runs the input channels in order, 0 ... 127 then 128 ... 255: member 0 owns the first half, so it
 // computes on what it wrote itself while the other half arrives; member 1 needs member 0's half first and runs one hand-off
 // behind, for the whole tower, not per layer.
 // Tags: layer l's output goes to exchange buffer l & 1; layers 0 and 37 tag bit 31 of a word, the others bit 15 with the
@@ -1536,7 +1542,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
             const int i = tid + k * 256, r = i >> 4, c16 = i & 15;
             u32x4 v = *(const u32x4*)(tout + r * 528 + half * 256 + c16 * 16);
             v[0] |= tag15 | tag31; v[2] |= tag15 | tag31;
-            __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, ex_out, i * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, ex_out, i * 16, 0, DIEE_PAIR_STORE_AUX);
         }
     }
 }
