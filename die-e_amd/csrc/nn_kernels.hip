@@ -46,6 +46,12 @@
                                   // does NOT share an XCD never sees plain data: its polls time out, the engine reports it and falls back (tags per
                                   // 8 bytes: nothing stale is ever taken)
 #endif
+#ifndef DIEE_PAIR_PF
+#define DIEE_PAIR_PF 6            // pair tower: weight k-steps in flight per wave and column fragment
+#endif
+#ifndef DIEE_PAIR_AHEAD
+#define DIEE_PAIR_AHEAD 1         // pair tower: the other member's half requested ahead of its use (see pair_layer)
+#endif
 #ifndef DIEE_PAIR_ABLATE
 #define DIEE_PAIR_ABLATE 0        // timing builds (wrong results): 1 = members do not wait for each other (one unchecked read), 2 = no exchange at all
 #endif
@@ -1449,10 +1455,15 @@ __device__ __forceinline__ void st_coherent8(__amdgpu_buffer_rsrc_t r, int byte_
     __builtin_amdgcn_raw_buffer_store_b64(rb_u32x2{v.x, v.y}, r, byte_off, 0, 16);       // sc1: write-through
 }
 
-template <bool RES, int PF, class Fetch>
+// fetch_peer(): the other member's half of this layer's input -> tin (blocks until it is there).  DIEE_PAIR_AHEAD: issue_peer()
+// requests it an eighth of a layer ahead of its use in member 0 (the reply travels while the MFMAs run; earlier, the bytes are
+// not there yet), issue_next() requests member 1's NEXT input as soon as it has published (member 0 finished that layer one
+// hand-off ago); fetch_peer() then finds its chunks in registers and only re-reads what had not landed.
+template <bool RES, int PF, class Fetch, class Issue, class IssueNext>
 __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* wp, const u32x4* wp_next, const float* __restrict__ bias,
                                            const uint32_t (&basep)[9][3], u32x4 (&bq)[PF][2], int lane, int wave, int half,
-                                           __amdgpu_buffer_rsrc_t ex_out, uint32_t tag15, uint32_t tag31, bool publish, Fetch&& fetch_peer) {
+                                           __amdgpu_buffer_rsrc_t ex_out, uint32_t tag15, uint32_t tag31, bool publish, Fetch&& fetch_peer,
+                                           Issue&& issue_peer, IssueNext&& issue_next) {
     constexpr int MF = 6, NQ = 2;
     f32x4 acc[MF][NQ];
 #pragma unroll
@@ -1476,6 +1487,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
         for (int u = 0; u < 18; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
             const int csn = it * 2 + un / 9;                      // 8 on the very last step: reads padding, unused
+            if (DIEE_PAIR_AHEAD && u == 9 && it == 1 && half == 0) issue_peer();
 #pragma unroll
             for (int f = 0; f < MF; ++f)
                 if (!border_skip(true, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
@@ -1545,6 +1557,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
             __builtin_amdgcn_raw_buffer_store_b128(rb_u32x4{v[0], v[1], v[2], v[3]}, ex_out, i * 16, 0, DIEE_PAIR_STORE_AUX);
         }
     }
+    if (DIEE_PAIR_AHEAD && half == 1) issue_next();
 }
 
 template <int PF>
@@ -1668,37 +1681,50 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
     // exchange buffers of this pair
     const __amdgpu_buffer_rsrc_t rex = coherent_rsrc(ex, (int)(2 * kPairMaxGroups * 2 * kPairHalfBytes));
     auto ex_off = [&](int parity, int member) -> int { return (int)((((size_t)parity * kPairMaxGroups + grp) * 2 + member) * kPairHalfBytes); };
-    // the other member's output of layer w -> its columns of tile `tl` (all threads; bounded wait)
-    auto fetch = [&](char* tl, int w) {
+    // the other member's output of layer w -> its columns of tile `tl`: issue() requests this thread's six 16-byte chunks,
+    // finish() checks every granule's tag (chunks requested too early hold the previous layer's bytes: they are waited for on a
+    // sentinel and read again), stages the chunks and meets the workgroup
+    constexpr int NCH = ROWS * 16 / NT;                           // 96 rows x 256 B / 256 threads = 6
+    u32x4 pre[NCH];
+    bool have = false;
+    auto issue = [&](int w) {
+        if (DIEE_PAIR_ABLATE == 2) return;
+        const int src = ex_off(w & 1, half ^ 1);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) pre[k] = ld_coherent16(rex, src + (tid + k * NT) * 16);
+        have = true;
+    };
+    auto finish = [&](char* tl, int w) {
+        if (DIEE_PAIR_ABLATE == 2) return;
         const int src = ex_off(w & 1, half ^ 1);
         const bool t31 = w == 0 || w == 37;
-        const uint32_t want15 = t31 ? 0u : tag_of(w), mask = t31 ? 0x80000000u : 0x8000u, want = t31 ? 0x80000000u : want15;
-        constexpr int NCH = ROWS * 16 / NT;                       // 16-byte chunks per thread: 96 rows x 256 B / 256 threads = 6
-        u32x4 v[NCH];
-        // wait on ONE chunk per thread (the last of its share: 256 pollers x 6 chunks per poll from every workgroup of the chip
-        // is memory traffic the weight streams pay for), then take the whole share and check every granule
-        if (DIEE_PAIR_ABLATE == 2) return;
-        for (int spins = 0; !dead && DIEE_PAIR_ABLATE == 0; ++spins) {
-            const u32x4 p = ld_coherent16(rex, src + (tid + (NCH - 1) * NT) * 16);
-            if ((((p[0] ^ want) | (p[2] ^ want)) & mask) == 0u) break;
-            if (spins > kPairSpinLimit) { atomicOr(err, 4u); dead = true; break; }
-            __builtin_amdgcn_s_sleep(DIEE_PAIR_POLL_SLEEP);
-        }
+        const uint32_t mask = t31 ? 0x80000000u : 0x8000u, want = t31 ? 0x80000000u : tag_of(w);
         for (int spins = 0;; ++spins) {
+            if (have) {
+                uint32_t bad = 0u;
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) v[k] = ld_coherent16(rex, src + (tid + k * NT) * 16);
-            uint32_t bad = 0u;
+                for (int k = 0; k < NCH; ++k) bad |= (pre[k][0] ^ want) | (pre[k][2] ^ want);
+                if ((bad & mask) == 0u || dead || DIEE_PAIR_ABLATE) break;
+            }
+            // not there yet: wait on ONE chunk (256 pollers x 6 chunks per poll from every workgroup of the chip is memory traffic
+            // the weight streams pay for), then take the whole share again
+            for (; !dead && DIEE_PAIR_ABLATE == 0; ++spins) {
+                const u32x4 p = ld_coherent16(rex, src + (tid + (NCH - 1) * NT) * 16);
+                if ((((p[0] ^ want) | (p[2] ^ want)) & mask) == 0u) break;
+                if (spins > kPairSpinLimit) { atomicOr(err, 4u); dead = true; break; }
+                __builtin_amdgcn_s_sleep(DIEE_PAIR_POLL_SLEEP);
+            }
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) bad |= (v[k][0] ^ want) | (v[k][2] ^ want);
-            if ((bad & mask) == 0u || dead || DIEE_PAIR_ABLATE) break;
-            if (spins > kPairSpinLimit) { atomicOr(err, 4u); dead = true; break; }
-            __builtin_amdgcn_s_sleep(DIEE_CL_POLL_SLEEP);
+            for (int k = 0; k < NCH; ++k) pre[k] = ld_coherent16(rex, src + (tid + k * NT) * 16);
+            have = true;
+            if (spins > kPairSpinLimit) { atomicOr(err, 4u); dead = true; }
         }
+        have = false;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int i = tid + k * NT, r = i >> 4, c16 = i & 15;
-            v[k][0] &= ~0x80008000u; v[k][2] &= ~0x80008000u;
-            *(u32x4*)(tl + r * RS + (half ^ 1) * 256 + c16 * 16) = v[k];
+            pre[k][0] &= ~0x80008000u; pre[k][2] &= ~0x80008000u;
+            *(u32x4*)(tl + r * RS + (half ^ 1) * 256 + c16 * 16) = pre[k];
         }
         __syncthreads();
     };
@@ -1713,16 +1739,18 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
         {
             const __amdgpu_buffer_rsrc_t out = coherent_rsrc((uint16_t*)((char*)ex + ex_off(l1 & 1, half)), (int)kPairHalfBytes);
             pair_layer<false, PF>(tx, th, w1, w2, bias + l1 * 256, basep, bq, lane, wave, half, out, l1 == 0 ? 0u : tag_of(l1),
-                                  l1 == 0 ? 0x80000000u : 0u, true, [&] { if (l1 > 0) fetch(tx, l1 - 1); });
+                                  l1 == 0 ? 0x80000000u : 0u, true, [&] { if (l1 > 0) finish(tx, l1 - 1); }, [&] { if (l1 > 0) issue(l1 - 1); },
+                                  [&] { issue(l1); });
         }
         {
             const __amdgpu_buffer_rsrc_t out = coherent_rsrc((uint16_t*)((char*)ex + ex_off(l2 & 1, half)), (int)kPairHalfBytes);
             pair_layer<true, PF>(th, tx, w2, w3, bias + l2 * 256, basep, bq, lane, wave, half, out, l2 == 37 ? 0u : tag_of(l2),
-                                 l2 == 37 ? 0x80000000u : 0u, !(l2 == 37 && half == 0), [&] { fetch(th, l2 - 1); });
+                                 l2 == 37 ? 0x80000000u : 0u, !(l2 == 37 && half == 0), [&] { finish(th, l2 - 1); }, [&] { issue(l2 - 1); },
+                                 [&] { if (l2 < 37) issue(l2); });
         }
     }
     if (half == 1) return;                                        // the head convs run on member 0
-    fetch(tx, 37);
+    finish(tx, 37);
     {
         // ---- head convs (nnet.rs:76-78, 88-90): three 16-column fragments over the whole K, waves 0 .. 2 (k_tower16's head section
         // at four waves: same arithmetic); everything per lane derived again from an opaque copy of the thread id (see there)
@@ -1945,7 +1973,7 @@ static void tower16p_launch(hipStream_t st, const void* wt16, const float* bias,
 bool launch_tower_pair(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                        const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err) {
     if (G > 4 * kPairMaxGroups) return false;
-    tower16p_launch<6>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
+    tower16p_launch<DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
     return true;
 }
 size_t tower_pair_exchange_bytes() { return 2 * (size_t)kPairMaxGroups * 2 * kPairHalfBytes; }
@@ -1967,7 +1995,7 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
         tower16_launch<4, 8, 6>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
                                 RowMap{row_slot, n_rows, 2, main_cap});
     if (pair_ex)      // the remainder of at most kRemSplit boards: the pair tower
-        tower16p_launch<6>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
+        tower16p_launch<DIEE_PAIR_PF>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
                            pair_ex, err, RowMap{row_slot, n_rows, 3, main_cap});
     else
         tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,
