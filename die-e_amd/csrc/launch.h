@@ -66,10 +66,10 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
                           const uint32_t* row_slot, const uint32_t* n_rows, uint16_t* pair_ex = nullptr, uint32_t* err = nullptr);
 // pair tower (k_tower16p): the fused tower with 4 boards per PAIR of workgroups, 257 ... 512 boards; `ex` = tower_pair_exchange_bytes()
 // of zeroed device memory, `err` gets bit 2 set if a hand-over timed out.  false = too many boards.
-bool launch_tower_pair(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
+bool launch_tower_pair(hipStream_t st, int boards_per_pair /* 4 or 2 */, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                        const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err);
 size_t tower_pair_exchange_bytes();
-int tower_pair_max_boards();
+int tower_pair_max_boards(int boards_per_pair);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
                           float* value, int G);
 

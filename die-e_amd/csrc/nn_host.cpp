@@ -361,11 +361,12 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (cluster(states_dev, W.cluster_heads)) { kind = 2; done = true; heads_done = fc_done = W.cluster_heads; }
         else if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
     }
-    if (!done && tgeom == 10) {
-        // 257 ... 512 boards: the fused tower on pairs of workgroups (init block and head convs inside)
+    if (!done && (tgeom == 10 || tgeom == 11)) {
+        // 257 ... 512 boards: the fused tower on pairs of workgroups, 4 boards per pair (10; 11: 2 boards per pair); init block and head convs inside
+        const int bpp = tgeom == 10 ? 4 : 2;
         stamp0();
-        if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards() &&
-            launch_tower_pair(st, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p, hp, hv, pair_exchange(e), e.flags_dev.p)) {
+        if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards(bpp) &&
+            launch_tower_pair(st, bpp, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p, hp, hv, pair_exchange(e), e.flags_dev.p)) {
             done = true; heads_done = true; W.cluster_used = true;    // (its hand-overs report through the same flag bit as the cluster tower's)
         } else {
             if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
@@ -567,7 +568,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
     const auto saved_cl = W.cluster_table;
-    if (variant >= 100 && variant <= 110) W.tower_table = {{0, variant - 100}};
+    if (variant >= 100 && variant <= 111) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
     if (variant == 201 || variant == 202 || variant == 204 || variant == 208) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();

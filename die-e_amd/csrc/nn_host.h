@@ -21,7 +21,8 @@ struct NetWeights {
     // 4 boards per workgroup above 416 boards (border-aware fragment order: 22 % of the MFMAs are padding and not issued;
     // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
-    std::vector<TowerRule> tower_table = {{928, 8}, {512, 6}, {256, 10}};     // 10 = the pair tower (k_tower16p), 257 ... 512 boards
+    std::vector<TowerRule> tower_table = {{928, 8}, {512, 6}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
+                                    // pair (257 ... 512 boards) / 2 boards per pair (129 ... 256: 277 ... 298 us against the cluster tower's 313 ... 318)
     DevBuf<uint16_t> pair_ex;       // its exchange buffers (zeroed once)
     bool pair_tower = true;         // DIEE_TOWER_PAIR=0: the 2-board geometry instead (rounds 1-2)
     bool invariant = false;         // DIEE_FLAG_INVARIANT_NN / diee_set_invariant_nn: every batch size on the fused 16x16x32 tower

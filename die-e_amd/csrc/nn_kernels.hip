@@ -1459,12 +1459,13 @@ __device__ __forceinline__ void st_coherent8(__amdgpu_buffer_rsrc_t r, int byte_
 // requests it an eighth of a layer ahead of its use in member 0 (the reply travels while the MFMAs run; earlier, the bytes are
 // not there yet), issue_next() requests member 1's NEXT input as soon as it has published (member 0 finished that layer one
 // hand-off ago); fetch_peer() then finds its chunks in registers and only re-reads what had not landed.
-template <bool RES, int PF, class Fetch, class Issue, class IssueNext>
+template <bool RES, int GT, int PF, class Fetch, class Issue, class IssueNext>
 __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* wp, const u32x4* wp_next, const float* __restrict__ bias,
-                                           const uint32_t (&basep)[9][3], u32x4 (&bq)[PF][2], int lane, int wave, int half,
+                                           const uint32_t (&basep)[9][(GT * 24 / 16 + 1) / 2], u32x4 (&bq)[PF][2], int lane, int wave, int half,
                                            __amdgpu_buffer_rsrc_t ex_out, uint32_t tag15, uint32_t tag31, bool publish, Fetch&& fetch_peer,
                                            Issue&& issue_peer, IssueNext&& issue_next) {
-    constexpr int MF = 6, NQ = 2;
+    constexpr int ROWS = GT * 24, MF = ROWS / 16, NQ = 2;
+    constexpr bool SP = GT == 4;                                  // border-aware fragment order (4 boards: see border_skip)
     f32x4 acc[MF][NQ];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
@@ -1475,13 +1476,13 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
     if (half == 1) fetch_peer();                                  // member 1: input channels 0 ... 127 are the other member's
 #pragma unroll
     for (int f = 0; f < MF; ++f)
-        if (!border_skip(true, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
+        if (!border_skip(SP, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
     for (int it = 0; it < 4; ++it) {
         if (it == 2 && half == 0) {                               // member 0: the second half of K is the other member's
             fetch_peer();
 #pragma unroll
             for (int f = 0; f < MF; ++f)                          // (the first fragments of this half were read ahead, before they had landed)
-                if (!border_skip(true, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f) + 4 * 64);
+                if (!border_skip(SP, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f) + 4 * 64);
         }
 #pragma unroll
         for (int u = 0; u < 18; ++u) {
@@ -1490,7 +1491,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
             if (DIEE_PAIR_AHEAD && u == 9 && it == 1 && half == 0) issue_peer();
 #pragma unroll
             for (int f = 0; f < MF; ++f)
-                if (!border_skip(true, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
+                if (!border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
             bf16x8 b[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
@@ -1502,13 +1503,13 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
             }
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                if (border_skip(true, u % 9, f)) continue;
+                if (border_skip(SP, u % 9, f)) continue;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);     // D = W^T x act^T
             }
             {
-                const int n_mfma = border_live(true, u % 9, MF) * NQ, n_lds = border_live(true, un % 9, MF);
+                const int n_mfma = border_live(SP, u % 9, MF) * NQ, n_lds = border_live(SP, un % 9, MF);
 #pragma unroll
                 for (int i = 0; i < MF * NQ; ++i) {
                     if (i >= n_mfma) break;
@@ -1528,7 +1529,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
         const float4 bv = *(const float4*)(bias + n0);
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int r = tower_row<true>(f, lane & 15);
+            const int r = tower_row<SP>(f, lane & 15);
             const int off = r * 528 + n0 * 2;
             float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
             if (RES) {
@@ -1550,7 +1551,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
     if (publish && DIEE_PAIR_ABLATE != 2) {
         const int tid = wave * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < ROWS * 16 / 256; ++k) {
             const int i = tid + k * 256, r = i >> 4, c16 = i & 15;
             u32x4 v = *(const u32x4*)(tout + r * 528 + half * 256 + c16 * 16);
             v[0] |= tag15 | tag31; v[2] |= tag15 | tag31;
@@ -1560,13 +1561,14 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
     if (DIEE_PAIR_AHEAD && half == 1) issue_next();
 }
 
-template <int PF>
+template <int GT, int PF>
 __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, const float* __restrict__ bias, int M, RowMap rm,
                                                   const BgState* __restrict__ states, const u32x4* __restrict__ winit, const float* __restrict__ binit,
                                                   const u32x4* __restrict__ whead, const float* __restrict__ bhead,
                                                   uint16_t* __restrict__ hp, float* __restrict__ hv,
                                                   uint16_t* ex /* [2][kPairMaxGroups][2][96][128] bf16 */, uint32_t* err) {
-    constexpr int GT = 4, ROWS = 96, MF = 6, RS = 528, NT = 256;
+    constexpr int ROWS = GT * 24, MF = ROWS / 16, RS = 528, NT = 256;
+    constexpr bool SP = GT == 4;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 34 + 128 + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tx = smem;
@@ -1617,15 +1619,15 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
         char* tl = i < 36 ? tx : th;
         *(u32x4*)(tl + ROWS * RS + (i % 36) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
-    uint32_t basep[9][3];
-    auto fill_basep = [&](uint32_t (&bp)[9][3], int ln) {
+    uint32_t basep[9][(MF + 1) / 2];
+    auto fill_basep = [&](uint32_t (&bp)[9][(MF + 1) / 2], int ln) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int h = 0; h < 3; ++h) bp[t][h] = 0;
+            for (int h = 0; h < (MF + 1) / 2; ++h) bp[t][h] = 0;
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int R = tower_row<true>(f, ln & 15);
+            const int R = tower_row<SP>(f, ln & 15);
             const int p = R % 24, y = p / 6, x = p % 6;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1652,7 +1654,7 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
                 for (int q = 0; q < 2; ++q) b[q] = __builtin_bit_cast(bf16x8, winit[((size_t)(wave * 4 + qq * 2 + q) * 9 + t) * 64 + lane]);
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
-                    if (border_skip(true, t, f)) continue;
+                    if (border_skip(SP, t, f)) continue;
                     const bf16x8 av = *(const bf16x8*)(th + baddr(t, f));
 #pragma unroll
                     for (int q = 0; q < 2; ++q) acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], av, acc[f][q], 0, 0, 0);
@@ -1664,7 +1666,7 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
                 const float4 bv = *(const float4*)(binit + n0);
 #pragma unroll
                 for (int f = 0; f < MF; ++f) {
-                    const int r = tower_row<true>(f, lane & 15);
+                    const int r = tower_row<SP>(f, lane & 15);
                     float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
                     const bool live = row0 + r < M;
                     v0 = v0 > 0.0f && live ? v0 : 0.0f; v1 = v1 > 0.0f && live ? v1 : 0.0f;
@@ -1738,13 +1740,13 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
         // both members computed the whole init block)
         {
             const __amdgpu_buffer_rsrc_t out = coherent_rsrc((uint16_t*)((char*)ex + ex_off(l1 & 1, half)), (int)kPairHalfBytes);
-            pair_layer<false, PF>(tx, th, w1, w2, bias + l1 * 256, basep, bq, lane, wave, half, out, l1 == 0 ? 0u : tag_of(l1),
+            pair_layer<false, GT, PF>(tx, th, w1, w2, bias + l1 * 256, basep, bq, lane, wave, half, out, l1 == 0 ? 0u : tag_of(l1),
                                   l1 == 0 ? 0x80000000u : 0u, true, [&] { if (l1 > 0) finish(tx, l1 - 1); }, [&] { if (l1 > 0) issue(l1 - 1); },
                                   [&] { issue(l1); });
         }
         {
             const __amdgpu_buffer_rsrc_t out = coherent_rsrc((uint16_t*)((char*)ex + ex_off(l2 & 1, half)), (int)kPairHalfBytes);
-            pair_layer<true, PF>(th, tx, w2, w3, bias + l2 * 256, basep, bq, lane, wave, half, out, l2 == 37 ? 0u : tag_of(l2),
+            pair_layer<true, GT, PF>(th, tx, w2, w3, bias + l2 * 256, basep, bq, lane, wave, half, out, l2 == 37 ? 0u : tag_of(l2),
                                  l2 == 37 ? 0x80000000u : 0u, !(l2 == 37 && half == 0), [&] { finish(th, l2 - 1); }, [&] { issue(l2 - 1); },
                                  [&] { if (l2 < 37) issue(l2); });
         }
@@ -1757,7 +1759,7 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
         int htid = tid;
         asm volatile("" : "+v"(htid));
         const int lane = htid & 63, wave = __builtin_amdgcn_readfirstlane(htid >> 6);
-        uint32_t basep[9][3];
+        uint32_t basep[9][(MF + 1) / 2];
         fill_basep(basep, lane);
         if (wave < 3) {
             auto baddr = [&](int t, int f) -> int { return (f & 1) ? (int)(basep[t][f >> 1] >> 16) : (int)(basep[t][f >> 1] & 0xffffu); };
@@ -1783,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int jf = 0; jf < MF; ++jf)
-                        if (!border_skip(true, t, jf)) acc[jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, ah[cur][jf], acc[jf], 0, 0, 0);
+                        if (!border_skip(SP, t, jf)) acc[jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, ah[cur][jf], acc[jf], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1791,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
             const float4 bv = *(const float4*)(bhead + n0);
 #pragma unroll
             for (int jf = 0; jf < MF; ++jf) {
-                const int r = tower_row<true>(jf, lane & 15);
+                const int r = tower_row<SP>(jf, lane & 15);
                 float v0 = acc[jf][0] + bv.x, v1 = acc[jf][1] + bv.y, v2 = acc[jf][2] + bv.z, v3 = acc[jf][3] + bv.w;
                 v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
                 if (n0 < 32) {
@@ -1954,30 +1956,32 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
 }
 
 // pair tower: 4 boards per pair of workgroups; the grid must be resident at once (one workgroup per CU, at most 256)
-template <int PF>
+template <int GT, int PF>
 static void tower16p_launch(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                             const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err,
                             const RowMap rm = RowMap{nullptr, nullptr, 0, 0}) {
     static bool attr_set = false;
-    constexpr int tile = ((96 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
+    constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_tower16p<PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_tower16p<GT, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int groups = (G + 3) / 4;
+    const int groups = (G + GT - 1) / GT;
     const int grid = 16 * ((groups + 7) / 8);                     // blockIdx -> (xcd, member, group): whole octets of pairs
-    hipLaunchKernelGGL((k_tower16p<PF>), dim3(grid), dim3(256), lds, st, (const u32x4*)wt16, bias, G * 24, rm, (const BgState*)states,
+    hipLaunchKernelGGL((k_tower16p<GT, PF>), dim3(grid), dim3(256), lds, st, (const u32x4*)wt16, bias, G * 24, rm, (const BgState*)states,
                        (const u32x4*)winit16, binit, (const u32x4*)whead16, bhead, hp, hv, ex, err);
 }
-bool launch_tower_pair(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
+bool launch_tower_pair(hipStream_t st, int boards_per_pair, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                        const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err) {
-    if (G > 4 * kPairMaxGroups) return false;
-    tower16p_launch<DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
+    if (G > boards_per_pair * kPairMaxGroups) return false;
+    if (boards_per_pair == 4) tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
+    else if (boards_per_pair == 2) tower16p_launch<2, DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
+    else return false;
     return true;
 }
 size_t tower_pair_exchange_bytes() { return 2 * (size_t)kPairMaxGroups * 2 * kPairHalfBytes; }
-int tower_pair_max_boards() { return 4 * kPairMaxGroups; }
+int tower_pair_max_boards(int boards_per_pair) { return boards_per_pair * kPairMaxGroups; }
 
 // The fused tower over a batch compacted on the device (see RowMap): up to three launches, each workgroup decides from
 // *n_rows whether it has work.  n_upper = the host's upper bound of n_rows (the number of live slots).
@@ -1995,7 +1999,7 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
         tower16_launch<4, 8, 6>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
                                 RowMap{row_slot, n_rows, 2, main_cap});
     if (pair_ex)      // the remainder of at most kRemSplit boards: the pair tower
-        tower16p_launch<DIEE_PAIR_PF>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
+        tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
                            pair_ex, err, RowMap{row_slot, n_rows, 3, main_cap});
     else
         tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,

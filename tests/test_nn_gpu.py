@@ -239,7 +239,7 @@ def test_cluster_tower_two_contexts_on_one_gpu(oracle):
 
 # ---- round 2: every dispatch path on >= 1024 states, the committed golden fixture, split launches ---------------------
 PATHS = [("k_tower16<4,8,3>", 1024), ("k_tower16<4,8,6>", 700), ("k_tower16<2,8,9>", 300),
-         ("k_tower_cl<8,4>", 200), ("k_tower_cl<4,8>", 100), ("k_tower_cl<2,8>", 50), ("k_tower_cl<1,8>", 20)]
+         ("k_tower16p<2> (pair tower, 2 boards per pair)", 200), ("k_tower_cl<4,8>", 100), ("k_tower_cl<2,8>", 50), ("k_tower_cl<1,8>", 20)]
 # measured on MI355X (round 2, 1024 mid-game states, random-init seed-0 net): see DESIGN.md section 2; bounds = 3 x measured
 PATH_POLICY_ATOL, PATH_VALUE_ATOL, PATH_POLICY_REL = 2e-5, 8e-3, 0.02
 
@@ -374,4 +374,12 @@ def test_pair_tower_is_bit_identical_to_the_fused_geometries(oracle, monkeypatch
         assert (p == p0).all() and (v == v0).all(), (G, float(np.abs(p - p0).max()))
     p1024 = ref.forward_t(np.concatenate([states, states]))[0]          # the 4-board one-pass kernel: the same bits again
     assert (p1024[:512] == pair.forward_t(states)[0]).all()
-    ref.close(); pair.close()
+    ref.close()
+    # 129 ... 256 boards: two boards per pair (dense row fragments), against the 2-board fused geometry forced for every size
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:3")
+    fused = diee_amd.Engine(0); fused.load_weights(blob)
+    for G in (129, 130, 131, 200, 255, 256) + tuple(int(x) for x in rng.integers(129, 257, size=20)):
+        p0, v0 = fused.forward_t(states[:G])
+        p, v = pair.forward_t(states[:G])
+        assert (p == p0).all() and (v == v0).all(), (G, float(np.abs(p - p0).max()))
+    fused.close(); pair.close()
