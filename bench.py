@@ -242,6 +242,7 @@ def main(argv=None, engine_factory=None):
                 # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
                 # which two processes on one GPU cannot promise each other
                 os.environ["DIEE_TOWER_CL"] = "none"
+                os.environ["DIEE_TOWER_PAIR"] = "0"     # (the pair tower hands over inside its launch too)
                 os.environ["DIEE_BN_COOP"] = "0"
             torch.cuda.set_device(dev)             # torch's HIP runtime initialises before libdiee.so's
         dist.init_process_group(backend)           # "nccl" is RCCL on ROCm

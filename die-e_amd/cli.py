@@ -133,6 +133,7 @@ def main(argv=None):
         device = local_rank % ndev
         if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
             os.environ["DIEE_TOWER_CL"] = "none"       # ranks share a GPU: no in-launch hand-overs between co-resident grids
+            os.environ["DIEE_TOWER_PAIR"] = "0"        # (the pair tower hands over inside its launch too)
             os.environ["DIEE_BN_COOP"] = "0"           # ... in the training step's BatchNorm passes either
         if torch.cuda.is_available():
             torch.cuda.set_device(device)

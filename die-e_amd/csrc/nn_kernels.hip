@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdio>
+#include <type_traits>
 
 #include "bg_device.h"
 #include "launch.h"
@@ -64,6 +65,12 @@
 #endif
 #ifndef DIEE_CL_PRIVATE
 #define DIEE_CL_PRIVATE 1         // cluster tower: every wave stages its own channel columns of the activation tile (no barrier between staging and the MFMA loop)
+#endif
+#ifndef DIEE_CL_LATE_OUT
+#define DIEE_CL_LATE_OUT DIEE_CL_LATE
+#endif
+#ifndef DIEE_CL_LATE_SLEEP
+#define DIEE_CL_LATE_SLEEP 0      // cluster tower: s_sleep argument (x 64 cycles) of the waves without output chunks in front of their late weight requests
 #endif
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
@@ -492,6 +499,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
     constexpr int LATE = KS == PF ? DIEE_CL_LATE : 0;   // of them, requested after the MFMA loop (see there); K split 4 ways: the ring covers half a layer, all inside
+    constexpr int LATE_OUT = KS == PF ? DIEE_CL_LATE_OUT : 0;     // the same for the waves that reduce and store (their late requests sit behind their stores)
     constexpr int PRS = kClusterPartStride;
     constexpr int TILE = ((ROWS + 1) * RS + 16 * 35 + 15) / 16 * 16;
     constexpr int PART = NSPLIT * MF * 32 * PRS;
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             base[t][f] = src * RS + (lane >> 5) * 16 + wave * (16 / NSPLIT) * 32;     // this wave's channel steps
         }
     }
+    const bool has_out = wave * 64 < ROWS * 4;      // this wave reduces and stores output chunks (wave-uniform)
     // this thread's output chunks (row, 8 channels) and their residual: the block input, kept in registers
     const __amdgpu_buffer_rsrc_t rX = coherent_rsrc(X, M * 512), rH = coherent_rsrc(H, M * 512);
     u32x4 resreg[CH];
@@ -745,25 +754,31 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         const u32x4* wn = l < 37 ? wp + (size_t)(l + 1) * kTowerLayerStride : (heads && nslice < 2) ? whp : wp + (size_t)37 * kTowerLayerStride;
 #endif
         const u32x4* wc = l < 38 ? wp + (size_t)l * kTowerLayerStride : whp;         // this layer's
+        // the ring runs ahead into the next layer.  A CU takes in weights at ~64 B/clk: a layer's 147 KB need ~2300 cycles of
+        // that pipe, the MFMA loop lasts ~1400 -- with every request inside the loop the waves queue at the pipe and the
+        // loop stretches to the stream's length (in-kernel stamps: loop + wait for the slowest wave 3100 cycles of a 6100-cycle
+        // layer).  The last LATE fragments per wave (needed last in the next loop) are requested after the loop instead,
+        // while two of the eight waves reduce the partial tiles and store: that part of the layer uses no memory pipe.
+        // (The count is a compile-time constant of the loop body: two instances, picked by the wave's role.)
+        auto mfma_loop = [&](auto late_c) {
+            constexpr int late_k = decltype(late_c)::value;
 #pragma unroll
-        for (int u = 0; u < (DIEE_CL_ABLATE == 1 ? 0 : KS); ++u) {
-            const int un = u + PD;
-            if (un < KS) {
+            for (int u = 0; u < (DIEE_CL_ABLATE == 1 ? 0 : KS); ++u) {
+                const int un = u + PD;
+                if (un < KS) {
 #pragma unroll
-                for (int f = 0; f < MF; ++f) a[un % NB][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+                    for (int f = 0; f < MF; ++f) a[un % NB][f] = *(const bf16x8*)(smem + base[un % 9][f] + (un / 9) * 32);
+                }
+                const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
+                if (DIEE_CL_ABLATE != 3 && (KS != PF || u < KS - late_k)) bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NB][f], b, acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const bf16x8 b = __builtin_bit_cast(bf16x8, bq[u % PF]);
-            // the ring runs ahead into the next layer.  A CU takes in weights at ~64 B/clk: a layer's 147 KB need ~2300 cycles of
-            // that pipe, the MFMA loop lasts ~1400 -- with every request inside the loop the waves queue at the pipe and the
-            // loop stretches to the stream's length (in-kernel stamps: loop + wait for the slowest wave 3100 cycles of a 6100-cycle
-            // layer).  The last LATE fragments per wave (needed last in the next loop) are requested after the loop instead,
-            // while two of the eight waves reduce the partial tiles and store: that part of the layer uses no memory pipe.
-            if (DIEE_CL_ABLATE != 3 && (KS != PF || u < KS - LATE)) bq[u % PF] = u + PF < KS ? wc[(u + PF) * 64] : wn[(u + PF - KS) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u % NB][f], b, acc[f], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (LATE == LATE_OUT || !has_out) mfma_loop(std::integral_constant<int, LATE>{});
+        else mfma_loop(std::integral_constant<int, LATE_OUT>{});
 
         if (ALIAS) __syncthreads();                 // every wave is done reading the activation tile
         CL_STAMP(2)                                 // MFMA loop + barrier
@@ -777,8 +792,8 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         if (DIEE_CL_ABLATE == 2) { float sink = 0.0f; for (int f = 0; f < MF; ++f) for (int i = 0; i < 16; ++i) sink += acc[f][i]; if (sink == 12345.678f) part[0] = 1; }
         __syncthreads();
         CL_STAMP(3)                                 // partial tiles written (barrier)
-        const bool has_out = wave * 64 < ROWS * 4;  // this wave reduces and stores output chunks (wave-uniform)
         if (LATE > 0 && !has_out && DIEE_CL_ABLATE != 3) {
+            if (DIEE_CL_LATE_SLEEP) __builtin_amdgcn_s_sleep(DIEE_CL_LATE_SLEEP);      // (measured: every delay here costs, 114.6 -> 117.5 / 121.3 / 123.1 us at 4 / 8 / 12)
 #pragma unroll
             for (int u = KS - LATE; u < KS; ++u) bq[u % PF] = wn[(u + PF - KS) * 64];
         }
@@ -824,9 +839,9 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
             o[0] |= tg; o[2] |= tg;
             st_coherent16(out, (egr * 256 + nslice * 32 + ec8 * 8) * 2, o);
         }
-        if (LATE > 0 && has_out && DIEE_CL_ABLATE != 3) {      // behind this wave's stores: they are what the other workgroups wait for
+        if (LATE_OUT > 0 && has_out && DIEE_CL_ABLATE != 3) {  // behind this wave's stores: they are what the other workgroups wait for
 #pragma unroll
-            for (int u = KS - LATE; u < KS; ++u) bq[u % PF] = wn[(u + PF - KS) * 64];
+            for (int u = KS - LATE_OUT; u < KS; ++u) bq[u % PF] = wn[(u + PF - KS) * 64];
         }
         CL_STAMP(4)                                 // reduce + store issued
         if (l == 0 || l == 37) {
