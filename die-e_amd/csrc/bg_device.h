@@ -133,7 +133,14 @@ __device__ __forceinline__ DKey key_init() {
 // get_valid_moves (backgammon_logic.rs:403-414) for ONE state by ONE wave (blockDim.x == 64).
 // Returns k; the plays are left in sc->play[0..k) in the reference's order.  *overflow is set when
 // the sequence table would overflow (never silent).
+// ONE_WAVE_BLOCK = false: the caller is one wave of a larger workgroup (the growth blocks inside the cluster-tower launch); every
+// meeting point then only orders this wave's own LDS accesses -- which execute in program order anyway -- for the compiler.
+template <bool ONE_WAVE_BLOCK = true>
 __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int lane, uint32_t* overflow) {
+    auto meet = [] {
+        if constexpr (ONE_WAVE_BLOCK) __syncthreads();
+        else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    };
     const int player = st_player(s);
     const int r0 = st_roll(s, 0), r1 = st_roll(s, 1);
     const int hi = r0 > r1 ? r0 : r1, lo = r0 > r1 ? r1 : r0;   // :406-409 dice = [max, min]
@@ -144,7 +151,7 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
 #pragma unroll
         for (int i = 0; i < 8; ++i) ((uint32_t*)sc->pts)[i] = s.w[i];
     }
-    __syncthreads();
+    meet();
     int v = 0;
     if (lane < 24) v = (int)(int8_t)sc->pts[lane] * player;      // own-signed count
     const uint32_t own = (uint32_t)__ballot(lane < 24 && v >= 1);
@@ -230,7 +237,7 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
         // dedup (:753-774) by comparing every lane's key with the keys of the lanes before it, broadcast one after the other
         // through v_readlane -- no hash table, no LDS atomics, one barrier instead of three per round.  The 128-bit delta key
         // has 77 significant bits (a: 12 x 3 + 5 bits of counters, b: 12 x 3): three dwords, compared exactly.
-        __syncthreads();
+        meet();
         uint64_t ka = 0, kb = 0;
         uint32_t mine = 0u;
         if (lane < S) { ka = sc->keyA[lane]; kb = sc->keyB[lane]; mine = sc->play[lane]; }
@@ -243,20 +250,20 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
         }
         const bool keep = lane < S && !dup;
         const unsigned long long bal = __ballot(keep);
-        __syncthreads();                                             // every lane holds its play: the list is rewritten in place
+        meet();                                             // every lane holds its play: the list is rewritten in place
         if (keep) sc->play[__popcll(bal & ((1ull << lane) - 1ull))] = mine;
-        __syncthreads();
+        meet();
         return __popcll(bal);
     }
     for (int i = lane; i < kTbl; i += 64) sc->owner[i] = kEmpty;
     for (int i = lane; i < S; i += 64) sc->status[i] = 0;
-    __syncthreads();
+    meet();
     for (int i = lane; i < S; i += 64) {
         const uint64_t a = sc->keyA[i], b = sc->keyB[i];
         uint64_t h = (a ^ (b * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
         sc->slot[i] = (uint16_t)((h >> 40) & (kTbl - 1));
     }
-    __syncthreads();
+    meet();
     // first-occurrence-wins dedup (:753-774).  Equal keys probe the same slots in the same rounds,
     // so the minimum ordinal of a key always wins the slot in the round its key first meets it.
     const uint32_t kFinal = 0x80000000u;
@@ -269,7 +276,7 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
             if (!(sc->owner[sl] & kFinal) || sc->owner[sl] == kEmpty) atomicMin(&sc->owner[sl], (uint32_t)i);
         }
         if (!__any(active)) break;
-        __syncthreads();
+        meet();
         for (int i = lane; i < S; i += 64) {
             if (sc->status[i] != 0) continue;
             const int sl = sc->slot[i];
@@ -278,10 +285,10 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
             else if (sc->keyA[o] == sc->keyA[i] && sc->keyB[o] == sc->keyB[i]) sc->status[i] = 2;
             else sc->slot[i] = (uint16_t)((sl + 1) & (kTbl - 1));
         }
-        __syncthreads();
+        meet();
         for (int i = lane; i < S; i += 64)
             if (sc->status[i] == 1) sc->owner[sc->slot[i]] = (uint32_t)i | kFinal;
-        __syncthreads();
+        meet();
     }
     // compact survivors in ordinal order (in place: output index <= input index)
     int k = 0;
@@ -291,11 +298,11 @@ __device__ inline int bg_legal_plays_wave(const BgState& s, WaveScratch* sc, int
         const uint32_t p = i < S ? sc->play[i] : 0u;
         const unsigned long long bal = __ballot(keep);
         const int pos = k + __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
+        meet();
         if (keep) sc->play[pos] = p;
         k += __popcll(bal);
     }
-    __syncthreads();
+    meet();
     return k;
 }
 

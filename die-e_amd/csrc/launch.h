@@ -18,6 +18,10 @@ void launch_wave_selftest(hipStream_t st, uint32_t* mismatches, uint32_t salt);
 void launch_probe_f32(hipStream_t st, const float* a, const float* b, uint32_t n, float* sq, float* dv, float* pw);
 void launch_probe_dice(hipStream_t st, uint64_t seed, const uint32_t* ctr, uint32_t n, uint8_t* dice, double* uni);
 
+// The network-independent half of expansion `it` (grow_slot, mcts_device.h) for the n slots of a search, as a request a network launch
+// may take along: the cluster tower runs it on extra workgroups of its own launch while the chip has CUs to spare.
+struct GrowReq { Tree T; Slots S; Segs G; uint32_t n, it; };
+
 // nn_kernels.hip
 void nn_setup_kernels();
 void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geometry (development)
@@ -38,7 +42,8 @@ constexpr int kClusterMaxGroups = 64;
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
                           const void* whead = nullptr, const float* bhead = nullptr, const void* wfc = nullptr, const float* bfc = nullptr,
-                          float* hv = nullptr, float* logits = nullptr);
+                          float* hv = nullptr, float* logits = nullptr, const GrowReq* grow = nullptr, bool* grown = nullptr);
+                          // grow: also grow the tree on extra workgroups if the whole grid stays resident (*grown tells)
 // train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 768 + 1280 floats of scratch)
 int train_stripes(int M);
 void launch_bn_relu_fwd(hipStream_t st, const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta, float* partial,

@@ -313,13 +313,18 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
                 if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
                 else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
                 const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits);
+                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &W.grow_done);
                 if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
                 return ok;
             }
         }
-        return launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                    whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits);
+        {
+            bool took = false;
+            const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
+                                                 whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took);
+            if (took) W.grow_done = true;
+            return ok;
+        }
     }
     return false;
 }

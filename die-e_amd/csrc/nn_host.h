@@ -6,6 +6,8 @@
 
 namespace diee {
 
+struct GrowReq;
+
 struct NetWeights {
     DevBuf<uint16_t> wconv[40];     // packed bf16 B fragments: 0 init, 39 heads (1..38 live in wtower)
     DevBuf<float> bconv[40];        // folded bias (1..38 live in btower)
@@ -47,6 +49,9 @@ struct NetWeights {
     // once, twice (rows in two chunks) or not at all (the cluster tower runs it itself)
     struct FcHook { void (*fn)(void* ctx, hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int G, const uint32_t* n_rows); void* ctx; };
     const FcHook* fc_hook = nullptr;
+    // the search's growth request for the evaluation about to be launched (launch.h GrowReq; null: none) and whether a launch took it
+    const struct GrowReq* grow_req = nullptr;
+    bool grow_done = false;
     bool cluster_heads = true;      // ... and the head convs and the policy FC (an evaluation below 257 boards = cluster launch + k_expand)
     DevBuf<uint16_t> wfc;           // policy FC fragments
     DevBuf<float> bfc, wv;          // policy FC bias [1376]; value FC weights [72] + bias

@@ -17,6 +17,7 @@
 
 #include "bg_device.h"
 #include "launch.h"
+#include "mcts_device.h"
 #include "nn_device.h"
 
 #ifndef DIEE_TOWER_SCHED
@@ -481,6 +482,7 @@ struct ClusterHeads {
     float* hv;              // [G][72]
     float* logits;          // [G][1352]
 };
+constexpr int kGrowLdsPerWave = (sizeof(WaveScratch) + 255) / 256 * 256;      // LDS of one growth wave
 constexpr int kFcRowStride = 1536 + 16;       // LDS stride of a board's 768 policy features (bank-conflict-free ds_read_b128 over boards)
 
 template <int GT, int NSPLIT>
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                                                           const BgState* __restrict__ states,    // non-null: the init block runs in here
                                                           const u32x4* __restrict__ winit,   // [8][9][64] x 16 B (k_conv3x3<16,...>'s fragments)
                                                           const float* __restrict__ binit,   // [256]
-                                                          ClusterHeads hd) {                 // whead non-null: head convs + policy FC in here
+                                                          ClusterHeads hd,                   // whead non-null: head convs + policy FC in here
+                                                          GrowReq gr, int tower_blocks) {    // tower_blocks > 0: the blocks behind them grow the tree
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
@@ -509,6 +512,15 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
     char* part = ALIAS ? smem : smem + TILE;        // [NSPLIT waves][MF*32 rows][32] f32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tower_blocks > 0 && (int)blockIdx.x >= tower_blocks) {
+        // ---- growth blocks (the search's request, launch.h): one wave per slot creates the children of the leaf the selection chose
+        // -- legal plays, codes, states, headers: everything of an expansion that does not wait for this very evaluation -- while the
+        // cluster workgroups evaluate it; k_expand<true> commits them with their priors afterwards.  These blocks share nothing with
+        // the tower's (the launcher keeps the whole grid resident: nobody waits for a block that cannot start).
+        const uint32_t slot = ((uint32_t)blockIdx.x - (uint32_t)tower_blocks) * NSPLIT + (uint32_t)wave;
+        grow_slot<false>(gr.T, gr.S, gr.G, gr.n, gr.it, slot, *(WaveScratch*)(smem + (size_t)wave * kGrowLdsPerWave));
+        return;
+    }
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
     const int nslice = j & 7, grp = xcd + 8 * (j >> 3);             // a whole cluster on one XCD (measured 5-8 % faster than
                                                                     // slice s of every group on XCD s, which would stream 1/8 of the weights per XCD)
@@ -1899,14 +1911,17 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 // runs the per-layer path)
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
-                            uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd) {
+                            uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd,
+                            const GrowReq* grow, bool* grown) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
-    constexpr int lds = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
+    constexpr int lds_tower = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
+    constexpr int lds_grow = NSPLIT * kGrowLdsPerWave;
+    constexpr int lds_max = lds_tower > lds_grow ? lds_tower : lds_grow;
     static int capacity_of[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};     // per device
     int& capacity = capacity_of[device & 15];
     if (capacity < 0) {
-        (void)hipFuncSetAttribute((const void*)k_tower_cl<GT, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_tower_cl<GT, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         // one workgroup per CU is always admitted (the occupancy API is not asked: with 160 KB of dynamic LDS
         // it answers 0 under some runtimes), and no geometry here needs more than one per CU
         int cus = 0;
@@ -1920,20 +1935,30 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
         told = true;
         return false;
     }
-    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid), dim3(64 * NSPLIT), lds, st, X, H, (const u32x4*)wt, bias, G * 24, groups, sync, err, g_tower_dbg,
-                       (const BgState*)states, (const u32x4*)winit, binit, hd);
+    // growth blocks ride along when the whole grid still fits the chip (one workgroup per CU): NSPLIT slots per block
+    int extra = 0;
+    if (grown) *grown = false;
+    if (grow && grow->n > 0) {
+        const int want = ((int)grow->n + NSPLIT - 1) / NSPLIT;
+        if (grid + want <= capacity) { extra = want; if (grown) *grown = true; }
+    }
+    const GrowReq none{};
+    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid + extra), dim3(64 * NSPLIT), extra ? lds_max : lds_tower, st, X, H, (const u32x4*)wt, bias, G * 24, groups,
+                       sync, err, g_tower_dbg, (const BgState*)states, (const u32x4*)winit, binit, hd, extra ? *grow : none, extra ? grid : 0);
     return true;
 }
 // whead != nullptr: the launch also runs the head convs and the policy FC (hv / logits are written; X holds no output then)
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
-                          const void* whead, const float* bhead, const void* wfc, const float* bfc, float* hv, float* logits) {
+                          const void* whead, const float* bhead, const void* wfc, const float* bfc, float* hv, float* logits,
+                          const GrowReq* grow, bool* grown) {
     const ClusterHeads hd{(const u32x4*)whead, bhead, (const u32x4*)wfc, bfc, hv, logits};
+    if (grown) *grown = false;
     switch (boards_per_group) {
-        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
-        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
-        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);
-        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd);     // K split over 4 waves (one per SIMD)
+        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }

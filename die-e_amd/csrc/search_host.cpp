@@ -218,11 +218,22 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
         else launch_policy_fc(hst, hp, wfc, bfc, logits, Gfc, n_rows);                 // (a second chunk of rows: the tree is grown already)
     }, &hc};
     struct HookScope { NetWeights* w; ~HookScope() { w->fc_hook = nullptr; } } scope{e.net};
+    // DIEE_CL_GROW (default on): below 129 boards the evaluation is ONE cluster-tower launch, latency-bound, with CUs to spare while
+    // fewer than ~28 games live (the tail of a batch: 130 of its 364 move-steps): the launch takes the growth along on extra
+    // workgroups (GrowReq) -- no second stream, no event --, and the k_expand behind it only has the priors, the backpropagation and
+    // the next descent left (16.2 -> 9.4 us on the chain between two evaluations).
+    static const bool cl_grow = env_u32("DIEE_CL_GROW", 1) != 0;
+    GrowReq greq{T, S, G, n, 0u};
+    struct GrowScope { NetWeights* w; ~GrowScope() { w->grow_req = nullptr; w->grow_done = false; } } gscope{e.net};
     auto forward = [&](uint32_t it, const NnRows* rws) {
         hc.it = it; hc.grown = false;
         e.net->fc_hook = (fc_grow && !split) ? &hook : nullptr;
+        greq.S = S; greq.it = it;
+        e.net->grow_req = (cl_grow && !split) ? &greq : nullptr;
+        e.net->grow_done = false;
         const bool compacted = nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr, rws);
-        e.net->fc_hook = nullptr;
+        e.net->fc_hook = nullptr; e.net->grow_req = nullptr;
+        if (e.net->grow_done) hc.grown = true;
         return compacted;
     };
     grow(kRootIteration);
