@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r03n_mfma_busy.json", "r03n_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (final build of round 3)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r03n_pmc_traffic.json", "r03n_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r03p_mfma_busy.json", "r03p_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (final build of round 3)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = "r03p_pmc_traffic.json", "r03p_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
 
 
 def host_cores():
@@ -315,7 +315,7 @@ def main(argv=None, engine_factory=None):
         exp_per_game = tot["expansions"] / max(games, 1)
         def pmc_traffic(name, fname=TRAFFIC_FILE):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/r03n_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
+            # (profiles/r03p_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
@@ -353,19 +353,19 @@ def main(argv=None, engine_factory=None):
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
                     "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"])}
         # the tower of 38 3x3 convs is ~90 % of the GPU time; it runs as ONE fused launch (k_tower16: activations in LDS)
-        # while more than 256 games are alive and as ONE cluster launch (k_tower_cl: 8-workgroup clusters per board group)
-        # at 256 games or fewer; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
+        # (k_tower16p: a board group over two workgroups, 129 ... 512 boards) while more than 128 games are alive and as ONE
+        # cluster launch (k_tower_cl: 8-workgroup clusters per board group) at 128 games or fewer; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
         # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch (33 % of the batch's
         # kernel time; 58 % of the default run's with the pipelined leg).  Its sampled launches are timed one to one, so
         # `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
-        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r03n_headline_kernel_stats.csv).  `roofline_other` keeps
+        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r03p_headline_kernel_stats.csv).  `roofline_other` keeps
         # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
         r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
                       tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"),
                       pmc_mfma("diee::k_tower16<4", MFMA_BUSY_FILE), MFMA_BUSY_FILE)
-        r_fused = roof("k_tower16 / k_tower16p, every geometry (<4,8,3>, <4,8,6>, pair tower <= 512 boards): all evaluations of batches > 256 boards, timed per evaluation (a compacted evaluation is up to three launches)",
+        r_fused = roof("k_tower16 / k_tower16p, every geometry (<4,8,3>, <4,8,6>, pair tower <4> at 257 ... 512 and <2> at 129 ... 256 boards): all evaluations of batches > 128 boards, timed per evaluation (a compacted evaluation is up to three launches)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
-        r_cluster = roof("k_tower_cl (38 tower layers + head convs + policy FC in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 256 boards; FLOPs counted: the 38 tower layers)",
+        r_cluster = roof("k_tower_cl (38 tower layers + head convs + policy FC in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound; batches <= 128 boards since the pair tower took 129 ... 256 (until then this row averaged over <= 256 boards); FLOPs counted: the 38 tower layers)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],
                          pmc_traffic("diee::k_tower_cl<1", TRAFFIC_FILE_32),
                          pmc_mfma("diee::k_tower_cl<1", MFMA_BUSY_FILE_32), MFMA_BUSY_FILE_32)
