@@ -57,6 +57,9 @@
 #ifndef DIEE_PAIR_ABLATE
 #define DIEE_PAIR_ABLATE 0        // timing builds (wrong results): 1 = members do not wait for each other (one unchecked read), 2 = no exchange at all
 #endif
+#ifndef DIEE_PAIR_RES
+#define DIEE_PAIR_RES 0           // timing builds (wrong results): the pair tower's K loop without its LDS reads / weight loads (see pair_layer)
+#endif
 #ifndef DIEE_PAIR_POLL_SLEEP
 #define DIEE_PAIR_POLL_SLEEP 4    // pair tower: s_sleep argument (x 64 cycles) between two polls of a member's sentinel chunk
 #endif
@@ -77,7 +80,7 @@
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
 #ifndef DIEE_TOWER_ABLATE
-#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights
+#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights, 6 ... 9 = fused tower without its LDS reads / weight loads (tower_layer16)
 #endif
 
 namespace diee {
@@ -1124,13 +1127,16 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
         for (int u = 0; u < 18; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
             const int csn = it * 2 + un / 9;                  // 8 on the very last step: reads padding, unused
+            // timing builds (wrong results): 6 / 9 = no LDS reads of the A fragments in the loop, 7 = every second k-step's only, 8 / 9 = no weight loads
+            constexpr bool kNoLds = DIEE_TOWER_ABLATE == 6 || DIEE_TOWER_ABLATE == 9, kNoW = DIEE_TOWER_ABLATE == 8 || DIEE_TOWER_ABLATE == 9;
+            const bool lds_step = !kNoLds && !(DIEE_TOWER_ABLATE == 7 && (u & 1));
 #pragma unroll
             for (int f = 0; f < MF; ++f)
-                if (!border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
+                if (lds_step && !border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
             bf16x8 b[NFR];
 #pragma unroll
             for (int q = 0; q < NFR; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
-            {
+            if (!kNoW) {
                 const int sp = it * 18 + u + PF;               // k-step to prefetch (of the next layer past 72)
                 const u32x4* src = sp < 72 ? wp + (size_t)sp * 64 : wp_next + (size_t)(sp - 72) * 64;
 #pragma unroll
@@ -1152,13 +1158,13 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             // interleave this k-step's loads between its MFMAs instead of issuing them as a block in front
             {
                 constexpr int dummy = 0; (void)dummy;
-                const int n_mfma = border_live(SP, u % 9, MF) * NFR, n_lds = border_live(SP, un % 9, MF);
+                const int n_mfma = border_live(SP, u % 9, MF) * NFR, n_lds = lds_step ? border_live(SP, un % 9, MF) : 0;
 #pragma unroll
                 for (int i = 0; i < MF * NFR; ++i) {
                     if (i >= n_mfma) break;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
                     if (i < n_lds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
-                    else if (i < n_lds + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    else if (!kNoW && i < n_lds + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1516,13 +1522,16 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
             const int cur = u & 1, nxt = cur ^ 1, un = u + 1;
             const int csn = it * 2 + un / 9;                      // 8 on the very last step: reads padding, unused
             if (DIEE_PAIR_AHEAD && u == 9 && it == 1 && half == 0) issue_peer();
+            // timing builds (wrong results): DIEE_PAIR_RES 1 = A fragments read on every second k-step only, 2 = never, 3 = no weight loads, 4 = neither
+            constexpr bool kNoW = DIEE_PAIR_RES == 3 || DIEE_PAIR_RES == 4;
+            const bool lds_step = !(DIEE_PAIR_RES == 2 || DIEE_PAIR_RES == 4) && !(DIEE_PAIR_RES == 1 && (u & 1));
 #pragma unroll
             for (int f = 0; f < MF; ++f)
-                if (!border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
+                if (lds_step && !border_skip(SP, un % 9, f)) a[nxt][f] = *(const bf16x8*)(tin + baddr(un % 9, f) + csn * 64);
             bf16x8 b[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
-            {
+            if (!kNoW) {
                 const int sp = it * 18 + u + PF;                  // k-step to prefetch (of the next layer past 72)
                 const u32x4* src = sp < 72 ? wp + (size_t)sp * 64 : wp_next + (size_t)(sp - 72) * 64;
 #pragma unroll
@@ -1536,13 +1545,13 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
                     acc[f][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[q], a[cur][f], acc[f][q], 0, 0, 0);     // D = W^T x act^T
             }
             {
-                const int n_mfma = border_live(SP, u % 9, MF) * NQ, n_lds = border_live(SP, un % 9, MF);
+                const int n_mfma = border_live(SP, u % 9, MF) * NQ, n_lds = lds_step ? border_live(SP, un % 9, MF) : 0;
 #pragma unroll
                 for (int i = 0; i < MF * NQ; ++i) {
                     if (i >= n_mfma) break;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (i < n_lds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (i < n_lds + NQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else if (!kNoW && i < n_lds + NQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
