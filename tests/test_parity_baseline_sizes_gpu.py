@@ -9,8 +9,10 @@ run the geometry the metric is quoted on:
   * the same at 900 roots, where the engine COMPACTS the evaluation (k_row_map: rows of slots whose leaf was terminal
     are not evaluated above 256 live games; 929 ... 1024 run plain) -- compaction held to the oracle, not to itself;
   * diee_self_play vs oracle.self_play_parallel (alpha_parallel.rs:101-231): 1024 games played TO COMPLETION, the one
-    run that crosses every network dispatch band (k_tower16<4,8,3> -> <4,8,6> -> <2,8,9> -> k_tower_cl<8,4> ... <1,8>)
-    with the compaction switching off at 256 live games; ps / state / outcome / game / order and every counter equal.
+    run that crosses every network dispatch band (k_tower16<4,8,3> -> <4,8,6> -> pair tower k_tower16p<4> -> <2> ->
+    k_tower_cl<4,8> ... <1,8>, with and without the growth workgroups in the cluster launch) with the compaction
+    switching off at 256 live games; ps / state / outcome / game / order and every counter equal;
+  * 1024 roots x iterations = 1600 (configs[3]: the deep tree, 205 k-node arenas) once, quirks on.
 
 The oracle's evaluator is the engine's own ResNet called back through diee_nn_forward on the same batch the reference
 would push (all N slots), so both sides see identical priors and values; everything else is the oracle's C restatement
@@ -84,6 +86,15 @@ def test_mcts_batch_bit_exact_at_baseline_size(eng, oracle, n, iters, quirks):
     assert os_["nn_evals"] == (iters + 1) * n
     assert os_["terminal_hits"] > iters * n // 8                 # the bear-off third keeps hitting terminal leaves ...
     assert os_["depth_sum"] > 2 * os_["selections"]              # ... and the search goes below the first level
+
+
+def test_mcts_batch_bit_exact_config4_1024x1600(eng, oracle):
+    """BASELINE configs[3]: iterations = 1600 at the full batch (1.6 M expansions in the C oracle, 1601 evaluations of 1024 boards)"""
+    n, iters = 1024, 1600
+    roots, probs, os_, r = run_both(eng, oracle, mixed_roots(oracle, n), iters, 1, step=1)
+    assert_search_equal(roots, probs, os_, r)
+    assert os_["nn_evals"] == (iters + 1) * n
+    assert os_["depth_sum"] > 2.5 * os_["selections"]            # the deep tree: mean leaf depth 2.9 (2.2 at iterations = 100)
 
 
 @pytest.mark.parametrize("quirks", [1, 0])
