@@ -144,3 +144,23 @@ def test_self_play_1024_games_round_limit_bit_exact(eng, oracle):
         for key in COUNTERS[:-1]:
             assert out["stats"][key] == ref["stats"][key], key
         assert (out["outcome"] == 0).any()
+
+
+def test_self_play_config2_whole_workload_bit_exact(eng, oracle):
+    """THE headline workload itself (BASELINE configs[1], what bench.py times): 1024 games x iterations = 100 to completion,
+    ~11 M expansions and ~37 k evaluations -- every record of the batch against the oracle's, bit for bit (about 2 minutes
+    of single-core C oracle; the engine's half takes 11 s)"""
+    n, iters = 1024, 100
+    ocfg, gcfg = cfgs(oracle, iters)
+    ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED + 29, gpu_eval(eng, oracle), None, ref_quirks=1, first_game_id=0)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 29, ref_quirks=True, first_game_id=0)
+    assert out["stats"]["move_steps"] == ref["steps"] > 250
+    assert len(out["outcome"]) == len(ref["outcome"]) > 90 * n
+    assert (out["game"] == ref["game"]).all()
+    assert (out["outcome"] == ref["outcome"]).all()
+    assert (out["state"].view(np.uint32) == ref["state"].view(np.uint32)).all()
+    assert (out["ps"].view(np.uint32) == ref["ps"].view(np.uint32)).all()
+    for key in COUNTERS[:-1]:
+        assert out["stats"][key] == ref["stats"][key], key
+    assert out["stats"]["plies"] == int(ref["plies"].sum())
+    assert out["stats"]["illegal_decodes"] == 0 == ref["stats"]["illegal_decodes"]
