@@ -377,6 +377,13 @@ class AlphaZero:
         only the new permutation travels to the device"""
         import torch
         n = len(memory["outcome"])
+        timing = os.environ.get("DIEE_TRAIN_TIMING") == "1"                     # wall clock of the call's phases on the log
+        t_ph = [time.time()]
+
+        def phase(name):
+            if timing:
+                torch.cuda.synchronize() if torch.cuda.is_available() else None
+                t_ph.append(time.time()); self.log(f"[train timing] {name}: {t_ph[-1] - t_ph[-2]:.2f} s")
         rng = rng or self.shuffle_rng                                           # a fresh permutation every call (every epoch)
         perm = rng.permutation(n)                                               # memory.shuffle(&mut rng), :203-204
         net = self.ddp or self.model
@@ -420,6 +427,7 @@ class AlphaZero:
             loss_buf = M["loss"] if len(M["loss"]) >= n_steps else torch.zeros(max(n_steps, 1), device=self.device)
         else:
             loss_buf = torch.zeros(max(n_steps, 1))                            # read back once: no host sync per step
+        phase("buffers + upload")
         use_graph = self.use_graph and n >= bs
         if use_graph:
             g = self._graphed_step(bs)
@@ -431,6 +439,7 @@ class AlphaZero:
         # read back once per epoch (no host sync per step), so the epoch runs on a snapshot: a non-finite loss anywhere in it
         # puts parameters, BatchNorm statistics and Adam's moments back to where the epoch started before anything is raised --
         # a caller that catches the exception holds the model it had, not one a NaN went through Adam on.
+        phase("capture + self-check")
         snap = self._snapshot()
 
         def run_epoch(use_graph):
@@ -455,6 +464,7 @@ class AlphaZero:
             return loss_buf[:n_steps].tolist()
 
         losses = run_epoch(use_graph)
+        phase(f"{n_steps} steps")
         if not np.isfinite(losses).all():
             self._restore(snap)
             # a starved one-launch BatchNorm pass (something else held CUs: another process, a collective) writes NaN
