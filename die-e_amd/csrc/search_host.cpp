@@ -222,7 +222,7 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     // fewer than ~28 games live (the tail of a batch: 130 of its 364 move-steps): the launch takes the growth along on extra
     // workgroups (GrowReq) -- no second stream, no event --, and the k_expand behind it only has the priors, the backpropagation and
     // the next descent left (16.2 -> 9.4 us on the chain between two evaluations).
-    static const bool cl_grow = env_u32("DIEE_CL_GROW", 1) != 0;
+    const bool cl_grow = env_u32("DIEE_CL_GROW", 1) != 0;        // (read per search: the tests switch it inside one process)
     GrowReq greq{T, S, G, n, 0u};
     struct GrowScope { NetWeights* w; ~GrowScope() { w->grow_req = nullptr; w->grow_done = false; } } gscope{e.net};
     auto forward = [&](uint32_t it, const NnRows* rws) {

@@ -271,3 +271,30 @@ def test_parent_walk_backpropagation_equals_the_recorded_path(oracle, monkeypatc
     for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
         assert a["stats"][key] == b["stats"][key], key
     assert a["stats"]["terminal_hits"] > 0 and a["stats"]["depth_sum"] > 2 * a["stats"]["selections"]     # deeper than every cap tried
+
+
+@pytest.mark.parametrize("n", [5, 20, 24, 40, 80])
+def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypatch, n):
+    """while the cluster tower's grid leaves CUs free (1 ... 24, 33 ... 48, 65 ... 96 boards) the launch grows the tree of
+    the leaf under evaluation on extra workgroups and k_expand<true> only commits the children; DIEE_CL_GROW=0 creates
+    them after the evaluation (k_expand<false>): same visit distributions, same counters -- bear-off roots keep terminal
+    and drained leaves (nothing to grow) in the mix, iterations = 60 reach arenas that are well filled"""
+    import diee_amd
+    walk = oracle.random_walk_states(77, 60)
+    late = walk[walk["off"].max(axis=1) >= 11][:n // 3]
+    states = np.concatenate([late, walk[120:120 + 4 * (n - len(late)):4]])
+    assert len(states) == n
+    _, gcfg = cfgs(oracle, 60)
+    gids = np.arange(n, dtype=np.uint32) + 11; rds = np.arange(n, dtype=np.uint32) % 5
+    e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+    res = []
+    for grow in ("1", "0"):
+        monkeypatch.setenv("DIEE_CL_GROW", grow)
+        res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 6, gids, rds, ref_quirks=True))
+    e.close()
+    a, b = res
+    assert a["probs"].tobytes() == b["probs"].tobytes() and (a["root_visits"] == b["root_visits"]).all()
+    assert (a["n_children"] == b["n_children"]).all()
+    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+        assert a["stats"][key] == b["stats"][key], key
+    assert a["stats"]["terminal_hits"] > 0
