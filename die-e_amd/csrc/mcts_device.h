@@ -35,7 +35,8 @@ constexpr uint32_t kRootIt = 0xFFFFFFFFu;
 // linked to the parent and `used` not advanced, so the tree is unchanged until k_expand<true> commits them with their priors.
 // Slots::grow_k = k (kNone: nothing to expand here, or no room), Slots::grow_code = the codes, four per lane.
 template <bool ONE_WAVE_BLOCK = true>
-__device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, uint32_t slot, WaveScratch& ws) {
+__device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, uint32_t slot, WaveScratch& ws,
+                                          uint32_t* hand = nullptr) {      // hand (LDS, 129 words): k and the codes for a wave of the SAME workgroup (k_expand<true, true>)
     if (slot >= n) return;
     const int lane = threadIdx.x & 63;
     const size_t base = (size_t)slot * T.node_cap;
@@ -49,14 +50,15 @@ __device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const S
     const BgState st = load_state(root ? &T.state[base] : &S.eval_states[slot]);
     const uint32_t if0 = root ? 1u : S.iter_flags[2 * ((size_t)seg * G.iter_cap + it)];
     const unsigned long long seed = G.seed[seg];
+    if (hand) __syncthreads();                               // k_expand<true, true>: wave 0 rewrites this slot's selection record after this point
     if (if0 == 0 || lterm || (m0 & kDrained)) {             // k_expand's `active`, `do_expand` and drained tests
-        if (lane == 0) S.grow_k[slot] = kNone;
+        if (lane == 0) { if (hand) hand[0] = kNone; else S.grow_k[slot] = kNone; }
         return;
     }
     int k = bg_legal_plays_wave<ONE_WAVE_BLOCK>(st, &ws, lane, S.overflow);
     if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }     // never silent: DIEE_ERR_CAPACITY
     if (first + (uint32_t)k > T.node_cap) {
-        if (lane == 0) { atomicOr(S.overflow, 2u); S.grow_k[slot] = kNone; }
+        if (lane == 0) { atomicOr(S.overflow, 2u); if (hand) hand[0] = kNone; else S.grow_k[slot] = kNone; }
         return;
     }
     const int r0 = st_roll(st, 0), r1 = st_roll(st, 1), player = st_player(st);
@@ -79,7 +81,13 @@ __device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const S
         T.visits[ci] = 0.0f; T.value[ci] = 0.0f;
         T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = code;
     }
-    *(uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) = make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
+    const uint2 packed = make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
+    if (hand) {
+        hand[1 + 2 * lane] = packed.x; hand[2 + 2 * lane] = packed.y;
+        if (lane == 0) hand[0] = (uint32_t)k;
+        return;
+    }
+    *(uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) = packed;
     if (lane == 0) S.grow_k[slot] = (uint32_t)k;
 }
 

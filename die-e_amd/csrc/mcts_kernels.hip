@@ -96,9 +96,14 @@ struct NodeHdr { uint32_t meta, first_child; float visits; };
 // backpropagation touches exactly one of them).  north_star: "UCB selection staged" -- in registers, one child per lane;
 // the levels below are reached through one round trip each.
 struct Level0 { float vis, val, pr; uint32_t cm, cf; BgState cs; bool valid; };
+// on_leaf(node, meta, first_child): the descent stands on a node without children; true = the caller had an expansion of exactly
+// this node pending and has committed it now (k_expand<true, true> descends while its second wave still creates the children):
+// meta / first_child are the node's new header and the descent goes on.
+struct NoLeafHook { __device__ __forceinline__ bool operator()(uint32_t, uint32_t&, uint32_t&) const { return false; } };
+template <class OnLeaf = NoLeafHook>
 __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const Segs& G, uint32_t slot, uint32_t seg, int lane,
                                             uint32_t it, float c, uint32_t quirks, uint32_t (&cn)[SC_COUNT], const NodeHdr* hdr,
-                                            const Level0* l0 = nullptr) {
+                                            const Level0* l0 = nullptr, OnLeaf&& on_leaf = OnLeaf()) {
     const size_t base = (size_t)slot * T.node_cap;
     uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);            // this batch's flags of iteration `it`
     uint32_t node = 0, depth = 0;
@@ -112,8 +117,13 @@ __device__ __forceinline__ void select_slot(const Tree& T, const Slots& S, const
 #pragma unroll
     for (int q = 0; q < 8; ++q) cur.w[q] = 0u;
     for (;;) {
-        const uint32_t k = meta_nch(mt);
-        if (k == 0) break;
+        uint32_t k = meta_nch(mt);
+        if (k == 0) {
+            uint32_t nm = 0, nf = 0;
+            if (!on_leaf(node, nm, nf)) break;
+            mt = nm; fc = nf; k = meta_nch(mt);
+            if (k == 0) break;
+        }
         const float sq = sqrtf(nvis);
         Best b{0.0f, -1};
         uint32_t bm = 0, bf = 0;                            // header, visits and state of this lane's best child
@@ -258,12 +268,35 @@ struct SettleScratch {
 constexpr uint32_t kNoNext = 0xFFFFFFFEu;
 // PRE: the children of the leaf were created by k_grow while the network ran (states, dice, parent, action code; priors open):
 // what is left for after the evaluation is what depends on it -- priors, the parent's link, backpropagation, the next descent.
-template <bool PRE>
-__global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
-                                               uint32_t next_it, float c) {
-    __shared__ typename std::conditional<PRE, SettleScratch, ExpandScratch>::type sc;
+// TWO (with PRE): two waves per slot.  Wave 1 creates the children (grow_slot) WHILE wave 0 loads, evaluates the value head, reduces
+// the softmax and backpropagates; they meet once, wave 1 hands k and the codes over in LDS, wave 0 commits the children with their
+// priors and descends.  Growth and backpropagation touch disjoint words of the tree (new nodes at [used, used + k) vs visits / value of
+// the path), so the order between them does not show in any result.
+struct TwoScratch {
+    SettleScratch s;
+    WaveScratch ws;
+    uint32_t hand[1 + 2 * 64];
+};
+template <bool PRE, bool TWO = false>
+__global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
+                                                           uint32_t next_it, float c) {
+    static_assert(PRE || !TWO, "two waves: the second one is the growth");
+    __shared__ typename std::conditional<TWO, TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type sc_all;
+    auto& sc = [&]() -> auto& { if constexpr (TWO) return sc_all.s; else return sc_all; }();
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
+    if constexpr (TWO) {
+        if (threadIdx.x >= 64) {
+            grow_slot<false>(T, S, G, n, it, slot, sc_all.ws, sc_all.hand);
+            __syncthreads();                                // the hand-over (wave 0 waits here when it has nothing left that does not need the children)
+            return;
+        }
+    }
+    // a wave's own LDS traffic: with two waves in the block a workgroup barrier would wait for the other one
+    auto meet = [&] {
+        if constexpr (TWO) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     EX_STAMP_INIT;
     const int lane = threadIdx.x;
     const size_t base = (size_t)slot * T.node_cap;
@@ -317,17 +350,38 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     }
     // lane of the root child on the recorded path of this slot's selection (depth 1), -1: the path ends at the root
     const int j1 = plen >= 2 ? __builtin_amdgcn_readlane((int)pnode, 1) - 1 : -1;
-    const uint32_t pre_k = PRE ? S.grow_k[slot] : kNone;
-    const uint2 pre_codes = PRE ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
+    uint32_t pre_k = (PRE && !TWO) ? S.grow_k[slot] : kNone;
+    uint2 pre_codes = (PRE && !TWO) ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
     const bool active = if0 != 0;                           // alpha_mcts.rs:170-172 `continue`
+    if constexpr (TWO) __syncthreads();                     // wave 1 has read the selection record this wave rewrites in its descent (see grow_slot)
     EX_STAMP(9);                                            // the first round of loads has landed
+    float v = 0.0f;
+    bool do_expand = true, do_backprop = !root;
+    float smM = 0.0f, smInv = 0.0f;
+    // backpropagation of this slot's selection (and the batch's stale initial slots, Q14)
+    auto bp_section = [&] {
+        if (do_backprop) {
+            if (plen) { backprop_path(T, base, pnode, lane, plen, v); if (lane == j1) { l0.vis += 1.0f; l0.val += v; } }
+            else { if (lane == 0) backprop(T, base, node, v); l0.valid = false; }
+            rh.visits += 1.0f;
+        }
+        if (!root && quirks && slot == seg_first && ifl.y != 0) {
+            // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
+            // i.e. the root in the batch's first slot, with the NN value of its state: the same chain of additions, on registers
+            const uint32_t cnt = ifl.y;
+            for (uint32_t i = 0; i < cnt; ++i) rh.visits += 1.0f;
+            if (lane == 0) {
+                float rvis = T.visits[base], rval = T.value[base];
+                for (uint32_t i = 0; i < cnt; ++i) { rvis += 1.0f; rval += rv0; }
+                T.visits[base] = rvis; T.value[base] = rval;
+            }
+        }
+    };
     if (active) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
     if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals0 + (seg_end - seg_first);
     if (root || S.slot_row == nullptr || !lterm) cn[SC_NN_ROWS] += 1;
 
-    float v = 0.0f;
-    bool do_expand = true, do_backprop = !root;
     if (!root) {
         if (lterm) {
             // stale selected_nodes_idxs slot (alpha_mcts.rs:142,192-200): re-"expanded" (no-op) and
@@ -351,14 +405,36 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
         if (lane == 0) S.root_value0[seg] = v0;
     }
     EX_STAMP(0);                                            // flags, value head, leaf meta
+    if constexpr (TWO) {
+        // everything that does not need the children, while wave 1 creates them
+        if (do_expand && !(m0 & kDrained)) {
+            softmax_reduce(lg, lane, smM, smInv);
+#pragma unroll
+            for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
+        }
+        bp_section();
+    }
+    }
+    // the commit of the children: with two waves it runs when the descent below stands on the leaf under expansion, or after it
+    uint32_t new_meta = 0, new_first = 0;
+    bool expanded = false, committed = false;
+    auto commit = [&] {
+    committed = true;
+    if constexpr (TWO) {
+        __syncthreads();                                    // wave 1's children are in the tree, k and the codes in LDS
+        pre_k = sc_all.hand[0];
+        pre_codes = make_uint2(sc_all.hand[1 + 2 * lane], sc_all.hand[2 + 2 * lane]);
+    }
+    if (active) {
     if constexpr (PRE) {
     if (do_expand && !(m0 & kDrained) && pre_k != kNone) {
         const int k = (int)pre_k;
-        float smM, smInv;                                    // softmax over this board's 1352 logits (nn_device.h)
-        softmax_reduce(lg, lane, smM, smInv);
+        if constexpr (!TWO) {
+            softmax_reduce(lg, lane, smM, smInv);            // softmax over this board's 1352 logits (nn_device.h)
 #pragma unroll
-        for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
-        __syncthreads();
+            for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
+            meet();
+        }
         EX_STAMP(2);                                        // softmax constants
         const float om = 1.0f - P.dir_eps;
 #pragma unroll
@@ -374,7 +450,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
                 sc.raw[j] = p;
             }
         }
-        __syncthreads();
+        meet();
         float pr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pr[r] = lane + 64 * r < k ? sc.raw[lane + 64 * r] : 0.0f;
@@ -398,6 +474,7 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
         if (plen == 2 && lane == j1) { l0.cm = nmeta; l0.cf = first; }          // the expanded leaf is a root child: its staged header
         cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
         if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
+        new_meta = nmeta; new_first = first; expanded = true;
     }
     } else {
     if (do_expand && !(m0 & kDrained)) {
@@ -467,32 +544,32 @@ __global__ __launch_bounds__(64) void k_expand(Tree T, Slots S, Segs G, uint32_t
     }
     }   // !PRE
     EX_STAMP(4);                                            // child creation (stores issued)
-    __syncthreads();
+    meet();
     EX_STAMP(5);                                            // ... stores acknowledged
-    if (do_backprop) {
-        if (plen) { backprop_path(T, base, pnode, lane, plen, v); if (lane == j1) { l0.vis += 1.0f; l0.val += v; } }
-        else { if (lane == 0) backprop(T, base, node, v); l0.valid = false; }
-        rh.visits += 1.0f;
-    }
-    if (!root && quirks && slot == seg_first && ifl.y != 0) {
-        // slots still holding the initial 0 index (alpha_mcts.rs:142) re-backpropagate node 0,
-        // i.e. the root in the batch's first slot, with the NN value of its state: the same chain of additions, on registers
-        const uint32_t cnt = ifl.y;
-        for (uint32_t i = 0; i < cnt; ++i) rh.visits += 1.0f;
-        if (lane == 0) {
-            float rvis = T.visits[base], rval = T.value[base];
-            for (uint32_t i = 0; i < cnt; ++i) { rvis += 1.0f; rval += rv0; }
-            T.visits[base] = rvis; T.value[base] = rval;
-        }
-    }
+    if constexpr (!TWO) bp_section();
     }   // active
+    };  // commit
+    if constexpr (!TWO) commit();
     EX_STAMP(6);                                            // backpropagation
     if (next_it != kNoNext) {
-        __syncthreads();                                    // lane 0's tree updates are visible to the whole wave
+        meet();                                             // lane 0's tree updates are visible to the whole wave
         EX_STAMP(7);
-        select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh, &l0);
+        if constexpr (TWO) {
+            l0.valid = false;                               // (the staged first level would miss the commit's header)
+            select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh, &l0, [&](uint32_t nd, uint32_t& nm, uint32_t& nf) {
+                if (committed || nd != node) return false;  // `node`: the leaf this launch expands (0 for a terminal selection: the root has children by then)
+                commit();
+                if (!expanded) return false;
+                meet();                                     // lane 0's header stores before the wave reads on
+                nm = new_meta; nf = new_first;
+                return true;
+            });
+        } else {
+            select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh, &l0);
+        }
         EX_STAMP(8);                                        // descent + leaf state + flags
     }
+    if constexpr (TWO) if (!committed) commit();
     if (lane == 0) store_counters(S, slot, cn);
 #ifdef DIEE_EXPAND_STAMPS
     if (threadIdx.x == 0) atomicAdd(&g_expand_stamps[15], 1ull);
@@ -795,8 +872,11 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 }
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown) {
-    if (pre_grown) hipLaunchKernelGGL(k_expand<true>, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
-    else hipLaunchKernelGGL(k_expand<false>, dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+    // DIEE_EXPAND2=0: one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
+    static const bool two = getenv("DIEE_EXPAND2") == nullptr || atoi(getenv("DIEE_EXPAND2")) != 0;
+    if (pre_grown) hipLaunchKernelGGL((k_expand<true, false>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+    else if (two) hipLaunchKernelGGL((k_expand<true, true>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
+    else hipLaunchKernelGGL((k_expand<false, false>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
 }
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
     hipLaunchKernelGGL(k_grow, dim3(n), dim3(64), 0, st, T, S, G, n, it);
