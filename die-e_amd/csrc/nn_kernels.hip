@@ -500,7 +500,8 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                                                           const u32x4* __restrict__ winit,   // [8][9][64] x 16 B (k_conv3x3<16,...>'s fragments)
                                                           const float* __restrict__ binit,   // [256]
                                                           ClusterHeads hd,                   // whead non-null: head convs + policy FC in here
-                                                          GrowReq gr, int tower_blocks) {    // tower_blocks > 0: the blocks behind them grow the tree
+                                                          GrowReq gr, int tower_blocks,      // tower_blocks > 0: the blocks behind them grow the tree
+                                                          int nx) {                          // XCDs that host clusters (8; fewer: DIEE_CL_PACK, see the launcher)
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
@@ -525,7 +526,15 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         return;
     }
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int nslice = j & 7, grp = xcd + 8 * (j >> 3);             // a whole cluster on one XCD (measured 5-8 % faster than
+    if (xcd >= nx) {
+        // packed clusters (nx < 8): the workgroups dispatched to the XCDs that host no cluster are the growth blocks
+        if (gr.n > 0) {
+            const uint32_t slot = (uint32_t)(j * (8 - nx) + (xcd - nx)) * NSPLIT + (uint32_t)wave;
+            grow_slot<false>(gr.T, gr.S, gr.G, gr.n, gr.it, slot, *(WaveScratch*)(smem + (size_t)wave * kGrowLdsPerWave));
+        }
+        return;
+    }
+    const int nslice = j & 7, grp = xcd + nx * (j >> 3);            // a whole cluster on one XCD (measured 5-8 % faster than
                                                                     // slice s of every group on XCD s, which would stream 1/8 of the weights per XCD)
     if (grp >= n_groups) return;
     const int row0 = grp * ROWS;
@@ -1937,7 +1946,14 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
         capacity = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? cus : 0;
     }
     const int groups = (G + GT - 1) / GT;
-    const int grid = 64 * ((groups + 7) / 8);
+    // Few clusters share few XCDs (DIEE_CL_PACK=0: one XCD per cluster, round 2's layout): up to 8 clusters on TWO XCDs, up to 16 on four
+    // -- at most 4 clusters = 32 workgroups per XCD, one per CU --, so that every XCD that streams the 44.8 MB of weights through its L2
+    // does it for up to four clusters (FETCH_SIZE per launch at 4 boards: 45 MB against 181 MB; at 16: 181 against 362) and the
+    // workgroups dispatched to the cluster-free XCDs are the growth blocks.  Measured per search iteration: 105.8 vs 108.4 us at 4 boards,
+    // 106.4 vs 111.3 at 8, 108.1 vs 110.6 at 16 (one XCD for 4 boards: 108.1; four XCDs for 8: 107.8; profiles/r03s_cl_pack_*).
+    static const bool pack = getenv("DIEE_CL_PACK") == nullptr || atoi(getenv("DIEE_CL_PACK")) != 0;
+    const int nx = !pack ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;
+    const int grid = 64 * ((groups + nx - 1) / nx);
     if (grid > capacity || groups > kClusterMaxGroups) {
         static bool told = false;
         if (!told) fprintf(stderr, "[diee] cluster tower <%d>: %d boards need %d resident workgroups, the device holds %d: using per-layer kernels\n", GT, G, grid, capacity);
@@ -1946,14 +1962,17 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
     }
     // growth blocks ride along when the whole grid still fits the chip (one workgroup per CU): NSPLIT slots per block
     int extra = 0;
+    bool ride = false;                                      // packed: the workgroups of the cluster-free XCDs grow (no extra blocks)
     if (grown) *grown = false;
     if (grow && grow->n > 0) {
         const int want = ((int)grow->n + NSPLIT - 1) / NSPLIT;
-        if (grid + want <= capacity) { extra = want; if (grown) *grown = true; }
+        if (nx < 8) ride = want <= (grid / 8) * (8 - nx);
+        else if (grid + want <= capacity) extra = want;
+        if (grown) *grown = ride || extra > 0;
     }
     const GrowReq none{};
-    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid + extra), dim3(64 * NSPLIT), extra ? lds_max : lds_tower, st, X, H, (const u32x4*)wt, bias, G * 24, groups,
-                       sync, err, g_tower_dbg, (const BgState*)states, (const u32x4*)winit, binit, hd, extra ? *grow : none, extra ? grid : 0);
+    hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid + extra), dim3(64 * NSPLIT), (extra || ride) ? lds_max : lds_tower, st, X, H, (const u32x4*)wt, bias, G * 24, groups,
+                       sync, err, g_tower_dbg, (const BgState*)states, (const u32x4*)winit, binit, hd, (extra || ride) ? *grow : none, extra ? grid : 0, nx);
     return true;
 }
 // whead != nullptr: the launch also runs the head convs and the policy FC (hv / logits are written; X holds no output then)
