@@ -737,8 +737,6 @@ __global__ void k_gather_roots(Games Gm, Slots S, Segs G, uint32_t n_live) {
 // the body of the per-game loop of self_play_parallel, alpha_parallel.rs:168-224
 __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, Segs G, uint32_t n_live, uint32_t step, PlayParams P) {
     __shared__ float row[1352];
-    __shared__ float sum_s;
-    __shared__ int chosen_s;
     const uint32_t slot = blockIdx.x;
     if (slot >= n_live) return;
     const int lane = threadIdx.x;
@@ -770,32 +768,48 @@ __global__ __launch_bounds__(64) void k_play_move(Tree T, Games Gm, Segs G, uint
     }
     // get_prob_tensor_parallel row (:164) and pow_(1/T) (:165), not renormalised (Q17)
     for (int a = lane; a < 1352; a += 64) row[a] = 0.0f;
-    if (lane == 0) {
-        float sm = 0.0f;
-        for (uint32_t j = 0; j < k; ++j) sm += T.visits[base + fc + j];
-        sum_s = sm;
+    // the children's visits and codes in one round of loads (k <= 256: four per lane); the row sum in child order on values broadcast
+    // from their lanes (the same chain of f32 additions in every lane)
+    float vis[4]; uint32_t cod[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t j = lane + 64 * r;
+        vis[r] = j < k ? T.visits[base + fc + j] : 0.0f;
+        cod[r] = j < k ? T.meta[base + fc + j] & 0xFFFFu : 0u;
     }
-    __syncthreads();
-    const float sum = sum_s;
-    for (uint32_t j = lane; j < k; j += 64)
-        row[T.meta[base + fc + j] & 0xFFFFu] = det_powf(T.visits[base + fc + j] / sum, P.inv_temperature);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kr = (int)k - 64 * r < 64 ? (int)k - 64 * r : 64;                    // uniform
+        for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vis[r]), j));
+    }
+    __syncthreads();                                            // (the zeroed row before the scattered weights)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if ((uint32_t)(lane + 64 * r) < k) row[cod[r]] = det_powf(vis[r] / sum, P.inv_temperature);
     __syncthreads();
     // weighted_select_tensor_idx (alphazero.rs:129-137): rand WeightedIndex over f64 weights
-    if (lane == 0) {
-        double total = 0.0;
-        for (int a = 0; a < 1352; ++a) total += (double)row[a];
-        const double x = draw_uniform(seed, gid, round, kTagSample, 0u) * total;
-        double cum = 0.0;
-        int pick = -1, last_nz = 0;
-        for (int a = 0; a < 1352; ++a) {
-            if (row[a] != 0.0f) last_nz = a;
+    // The f64 sums run over all 1352 weights in index order; at most k of them are not +0.0, and x + 0.0 == x exactly, so only those
+    // are added, in index order: one ballot per 64 codes finds them (1352 dependent f64 adds from LDS, twice, were ~85 us per move-step).
+    unsigned long long nzm[22];
+#pragma unroll
+    for (int q = 0; q < 22; ++q) nzm[q] = __ballot(64 * q + lane < 1352 && row[64 * q + lane] != 0.0f);
+    double total = 0.0;
+#pragma unroll
+    for (int q = 0; q < 22; ++q)
+        for (unsigned long long m = nzm[q]; m; m &= m - 1) total += (double)row[64 * q + __builtin_ctzll(m)];
+    const double x = draw_uniform(seed, gid, round, kTagSample, 0u) * total;
+    double cum = 0.0;
+    int pick = -1, last_nz = 0;
+#pragma unroll
+    for (int q = 0; q < 22; ++q)
+        for (unsigned long long m = nzm[q]; m && pick < 0; m &= m - 1) {
+            const int a = 64 * q + __builtin_ctzll(m);
+            last_nz = a;
             cum += (double)row[a];
-            if (cum > x) { pick = a; break; }
+            if (cum > x) pick = a;
         }
-        chosen_s = pick >= 0 ? pick : last_nz;
-    }
-    __syncthreads();
-    const uint32_t code = (uint32_t)chosen_s;
+    const uint32_t code = (uint32_t)(pick >= 0 ? pick : last_nz);        // (uniform: every lane ran the same chain)
     // MemoryFragment{outcome: player, ps, state} (:195-199)
     const uint32_t nf = Gm.nfrags[g];
     const size_t fi = (size_t)g * Gm.frag_cap + nf;
