@@ -373,6 +373,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards(bpp) &&
             launch_tower_pair(st, bpp, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p, hp, hv, pair_exchange(e), e.flags_dev.p)) {
             done = true; heads_done = true; W.cluster_used = true;    // (its hand-overs report through the same flag bit as the cluster tower's)
+            if (bpp == 2) kind = 2;                                    // the sampled timings go by band: <= 256 boards is the small-batch row
         } else {
             if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
             tgeom = 3;

@@ -61,7 +61,7 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower, 3 fused tower as one <4,8,3> launch, 2 cluster
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
                                     // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
     bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
     int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)

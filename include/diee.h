@@ -111,7 +111,7 @@ typedef struct {
     double   tower_seconds;    /* HIP-event time of sampled fused-tower launches (k_tower)  */
     uint64_t tower_launches;
     double   tower_flops;
-    double   cluster_seconds;  /* HIP-event time of sampled cluster-tower launches (k_tower_cl, small batches) */
+    double   cluster_seconds;  /* HIP-event time of sampled small-batch launches (<= 256 boards: k_tower_cl, k_tower16p<2>) */
     uint64_t cluster_launches;
     double   cluster_flops;
     uint64_t nn_rows;          /* rows the ResNet really evaluated: above 256 live games the rows of slots whose selected leaf
