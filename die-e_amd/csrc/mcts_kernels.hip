@@ -277,15 +277,17 @@ struct TwoScratch {
     WaveScratch ws;
     uint32_t hand[1 + 2 * 64];
 };
-template <bool PRE, bool TWO = false>
+// TWO == 2 (with PRE, the children exist already): wave 1 is the COMMIT wave -- softmax over the logits row, masked priors, the leaf's new
+// header -- while wave 0 evaluates the value head, backpropagates and descends; same meeting point, wave 1 hands the new header over.
+template <bool PRE, int TWO = 0>
 __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
                                                            uint32_t next_it, float c) {
     static_assert(PRE || !TWO, "two waves: the second one is the growth");
-    __shared__ typename std::conditional<TWO, TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type sc_all;
+    __shared__ typename std::conditional<(TWO != 0), TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type sc_all;
     auto& sc = [&]() -> auto& { if constexpr (TWO) return sc_all.s; else return sc_all; }();
     const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
-    if constexpr (TWO) {
+    if constexpr (TWO == 1) {
         if (threadIdx.x >= 64) {
             grow_slot<false>(T, S, G, n, it, slot, sc_all.ws, sc_all.hand);
             __syncthreads();                                // the hand-over (wave 0 waits here when it has nothing left that does not need the children)
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
         else __syncthreads();
     };
     EX_STAMP_INIT;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool main_wave = threadIdx.x < 64;                // (TWO == 2: wave 1 runs the loads below too, then only the commit)
     const size_t base = (size_t)slot * T.node_cap;
     const bool root = it == kRootIt;
     const bool quirks = P.quirks != 0;
@@ -350,13 +353,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     }
     // lane of the root child on the recorded path of this slot's selection (depth 1), -1: the path ends at the root
     const int j1 = plen >= 2 ? __builtin_amdgcn_readlane((int)pnode, 1) - 1 : -1;
-    uint32_t pre_k = (PRE && !TWO) ? S.grow_k[slot] : kNone;
-    uint2 pre_codes = (PRE && !TWO) ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
+    uint32_t pre_k = (PRE && TWO != 1) ? S.grow_k[slot] : kNone;
+    uint2 pre_codes = (PRE && TWO != 1) ? *(const uint2*)(S.grow_code + (size_t)slot * kMaxPlays + lane * 4) : make_uint2(0u, 0u);
     const bool active = if0 != 0;                           // alpha_mcts.rs:170-172 `continue`
     if constexpr (TWO) __syncthreads();                     // wave 1 has read the selection record this wave rewrites in its descent (see grow_slot)
-    EX_STAMP(9);                                            // the first round of loads has landed
     float v = 0.0f;
-    bool do_expand = true, do_backprop = !root;
+    bool do_expand = root || !lterm, do_backprop = !root;
     float smM = 0.0f, smInv = 0.0f;
     // backpropagation of this slot's selection (and the batch's stale initial slots, Q14)
     auto bp_section = [&] {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
             }
         }
     };
-    if (active) {
+    if (active && main_wave) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
     if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals0 + (seg_end - seg_first);
     if (root || S.slot_row == nullptr || !lterm) cn[SC_NN_ROWS] += 1;
@@ -406,8 +408,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     }
     EX_STAMP(0);                                            // flags, value head, leaf meta
     if constexpr (TWO) {
-        // everything that does not need the children, while wave 1 creates them
-        if (do_expand && !(m0 & kDrained)) {
+        // everything that does not need the children, while wave 1 creates (1) / commits (2) them
+        if (TWO == 1 && do_expand && !(m0 & kDrained)) {
             softmax_reduce(lg, lane, smM, smInv);
 #pragma unroll
             for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
@@ -420,16 +422,29 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     bool expanded = false, committed = false;
     auto commit = [&] {
     committed = true;
-    if constexpr (TWO) {
+    if constexpr (TWO == 1) {
         __syncthreads();                                    // wave 1's children are in the tree, k and the codes in LDS
         pre_k = sc_all.hand[0];
         pre_codes = make_uint2(sc_all.hand[1 + 2 * lane], sc_all.hand[2 + 2 * lane]);
+    }
+    if constexpr (TWO == 2) {
+        if (main_wave) {
+            __syncthreads();                                // wave 1 has committed the children: the leaf's new header in LDS
+            expanded = sc_all.hand[0] != 0u; new_meta = sc_all.hand[1]; new_first = sc_all.hand[2];
+            if (expanded) {
+                const uint32_t k = meta_nch(new_meta);
+                if (node == 0) { rh.meta = new_meta; rh.first_child = new_first; }
+                cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += k;
+                if (k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = k;
+            }
+            return;
+        }
     }
     if (active) {
     if constexpr (PRE) {
     if (do_expand && !(m0 & kDrained) && pre_k != kNone) {
         const int k = (int)pre_k;
-        if constexpr (!TWO) {
+        if constexpr (TWO != 1) {
             softmax_reduce(lg, lane, smM, smInv);            // softmax over this board's 1352 logits (nn_device.h)
 #pragma unroll
             for (int q = 0; q < 22; ++q) sc.lgs[lane + 64 * q] = lg[q];
@@ -550,6 +565,14 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     }   // active
     };  // commit
     if constexpr (!TWO) commit();
+    if constexpr (TWO == 2) {
+        if (!main_wave) {                                   // the commit wave: nothing else, then the hand-over
+            commit();
+            if (lane == 0) { sc_all.hand[0] = expanded ? 1u : 0u; sc_all.hand[1] = new_meta; sc_all.hand[2] = new_first; }
+            __syncthreads();
+            return;
+        }
+    }
     EX_STAMP(6);                                            // backpropagation
     if (next_it != kNoNext) {
         meet();                                             // lane 0's tree updates are visible to the whole wave
@@ -887,10 +910,13 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown) {
     // DIEE_EXPAND2=0: one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
+    // DIEE_EXPAND2C=0: children grown by the tower launch are committed by the one wave that does everything else too
     static const bool two = getenv("DIEE_EXPAND2") == nullptr || atoi(getenv("DIEE_EXPAND2")) != 0;
-    if (pre_grown) hipLaunchKernelGGL((k_expand<true, false>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
-    else if (two) hipLaunchKernelGGL((k_expand<true, true>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
-    else hipLaunchKernelGGL((k_expand<false, false>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+    static const bool two_c = getenv("DIEE_EXPAND2C") == nullptr || atoi(getenv("DIEE_EXPAND2C")) != 0;
+    if (pre_grown && two_c) hipLaunchKernelGGL((k_expand<true, 2>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
+    else if (pre_grown) hipLaunchKernelGGL((k_expand<true, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
+    else if (two) hipLaunchKernelGGL((k_expand<true, 1>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
+    else hipLaunchKernelGGL((k_expand<false, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
 }
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
     hipLaunchKernelGGL(k_grow, dim3(n), dim3(64), 0, st, T, S, G, n, it);
