@@ -336,7 +336,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     const uint32_t m0 = lterm ? 0u : m0q;
     const ValueHeadIn vh = value_head_load(S.hv + (size_t)row * 72, S.wv, lane);
     float lg[22];
-    softmax_load(S.logits + (size_t)row * 1352, lane, lg);
+    if (TWO != 2 || !main_wave) softmax_load(S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
+    else {
+#pragma unroll
+        for (int q = 0; q < 22; ++q) lg[q] = 0.0f;
+    }
     // k_grow's hand-over: how many children it created for this slot (kNone: none -- nothing to expand, or no room) and
     // their action codes, four per lane (child lane + 64 q in position q)
     // the root's children, one per lane, for the first level of the descent that follows (see Level0); patched below with
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
 #ifndef DIEE_STAGE_L0
 #define DIEE_STAGE_L0 0        // measured: +0.2 us per launch (the seven extra loads per lane cost more than the round trip they save; profiles/r03i_*): off
 #endif
-    l0.valid = DIEE_STAGE_L0 && !root && next_it != kNoNext;
+    l0.valid = (DIEE_STAGE_L0 == 1 || (DIEE_STAGE_L0 == 2 && TWO == 2 && main_wave)) && !root && next_it != kNoNext;
     {
         const size_t c0 = base + 1 + (l0.valid ? lane : 0);
         l0.vis = T.visits[c0]; l0.val = T.value[c0]; l0.pr = T.prior[c0]; l0.cm = T.meta[c0]; l0.cf = T.first_child[c0];
@@ -578,7 +582,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
         meet();                                             // lane 0's tree updates are visible to the whole wave
         EX_STAMP(7);
         if constexpr (TWO) {
-            l0.valid = false;                               // (the staged first level would miss the commit's header)
+            // (a staged first level holds the leaf's OLD header when the leaf is a root child: the descent then stands on a node
+            // without children there and commits, like everywhere else)
             select_slot(T, S, G, slot, seg, lane, next_it, c, P.quirks, cn, &rh, &l0, [&](uint32_t nd, uint32_t& nm, uint32_t& nf) {
                 if (committed || nd != node) return false;  // `node`: the leaf this launch expands (0 for a terminal selection: the root has children by then)
                 commit();
