@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r03t_mfma_busy.json", "r03t_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (final build of round 3)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r03t_pmc_traffic.json", "r03t_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r03x_mfma_busy.json", "r03x_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (final build of round 3)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = "r03x_pmc_traffic.json", "r03x_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
 
 
 def host_cores():
@@ -315,7 +315,7 @@ def main(argv=None, engine_factory=None):
         exp_per_game = tot["expansions"] / max(games, 1)
         def pmc_traffic(name, fname=TRAFFIC_FILE):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/r03t_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
+            # (profiles/r03x_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
@@ -359,7 +359,7 @@ def main(argv=None, engine_factory=None):
         # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch (33 % of the batch's
         # kernel time; 58 % of the default run's with the pipelined leg).  Its sampled launches are timed one to one, so
         # `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
-        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r03t_headline_kernel_stats.csv).  `roofline_other` keeps
+        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r03x_headline_kernel_stats.csv).  `roofline_other` keeps
         # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
         r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
                       tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"),
