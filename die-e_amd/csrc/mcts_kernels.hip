@@ -277,8 +277,9 @@ struct TwoScratch {
     WaveScratch ws;
     uint32_t hand[1 + 2 * 64];
 };
-// TWO == 2 (with PRE, the children exist already): wave 1 is the COMMIT wave -- softmax over the logits row, masked priors, the leaf's new
-// header -- while wave 0 evaluates the value head, backpropagates and descends; same meeting point, wave 1 hands the new header over.
+// TWO == 2 (with PRE, the children exist already): wave 1 is the COMMIT wave -- softmax over the logits row, masked priors of the children --
+// while wave 0 evaluates the value head, backpropagates and descends; same meeting point, wave 1 hands the leaf's new header over in LDS and
+// wave 0 stores it (the descent may be reading that header: nobody else may change it under its feet).
 template <bool PRE, int TWO = 0>
 __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
                                                            uint32_t next_it, float c) {
@@ -437,6 +438,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
             expanded = sc_all.hand[0] != 0u; new_meta = sc_all.hand[1]; new_first = sc_all.hand[2];
             if (expanded) {
                 const uint32_t k = meta_nch(new_meta);
+                if (lane == 0) {                            // the leaf's header: linked only now, by the wave that walks the tree
+                    T.first_child[base + node] = new_first;
+                    T.meta[base + node] = new_meta;
+                    T.used[slot] = new_first + k;
+                }
+                meet();
                 if (node == 0) { rh.meta = new_meta; rh.first_child = new_first; }
                 cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += k;
                 if (k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = k;
@@ -484,7 +491,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
         for (int r = 0; r < 4; ++r)
             if (lane + 64 * r < k) T.prior[base + first + lane + 64 * r] = pr[r] / sum;
         const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
-        if (lane == 0) {
+        // (TWO == 2: this is the commit wave; the main wave may be reading this very header in its descent, so the header is
+        // the main wave's to store, after the meeting point, when the priors above are visible to it)
+        if (lane == 0 && TWO != 2) {
             T.first_child[base + node] = first;
             T.meta[base + node] = nmeta;
             T.used[slot] = first + (uint32_t)k;
