@@ -234,9 +234,10 @@ def main(argv=None, engine_factory=None):
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
-        if backend == "nccl":
-            # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
-            ndev = max(torch.cuda.device_count(), 1)
+        # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" or ndev > 0:          # (gloo on a GPU box: ranks that share a device, tests/test_dist_gpu.py)
+            ndev = max(ndev, 1)
             dev = local_rank % ndev
             if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
                 # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,

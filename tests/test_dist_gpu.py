@@ -36,3 +36,25 @@ def test_bench_under_torch_distributed_run_world_size_1():
         assert dist_line["stats"][key] == plain["stats"][key], key
     assert abs(dist_line["stats"]["expansions_per_game"] - plain["stats"]["expansions_per_game"]) < 1e-9
     assert dist_line["config"]["parallelism"].startswith("dp1")
+
+
+def test_bench_two_ranks_on_the_one_gpu_over_gloo():
+    """world size 2 on hardware: two ranks share the box's one GPU (RCCL refuses two ranks per device, so the reductions go
+    over gloo: DIEE_BENCH_BACKEND); bench.py drops the co-residency kernels when ranks share a device.  Each rank plays its own
+    block of game ids on a real engine; the line carries both ranks' fragment counts and the sum of their games."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DIEE_BENCH_BACKEND="gloo")
+    args = ["--gpus", "2", "--steps", "1", "--iterations", "6", "--no-cpu-baseline", "--games", "16", "--pipeline", "0"]   # whole games: records exist
+    port = str(29900 + os.getpid() % 90)
+    rc, line, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, "bench.py"] + args, env)
+    assert rc == 0, err
+    assert line is not None, err
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"].startswith("dp2")
+    assert line["stats"]["games"] == 2 * 16
+    assert line["config"]["workload"].count("num_self_play_batches=16 per GPU") == 1
+    assert len(line["fragments_per_rank"]) == 2 and all(f > 0 for f in line["fragments_per_rank"])
+    assert sum(line["fragments_per_rank"]) == line["stats"]["fragments"]
+    # rank 0 alone plays the same first block of games: the two-rank line holds its records plus rank 1's
+    rc1, one, err1 = _run([sys.executable, "bench.py", "--gpus", "1"] + args[2:], dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert rc1 == 0 and one is not None, err1
+    assert one["stats"]["fragments"] == line["fragments_per_rank"][0]
