@@ -298,3 +298,32 @@ def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypa
     for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
         assert a["stats"][key] == b["stats"][key], key
     assert a["stats"]["terminal_hits"] > 0
+
+
+@pytest.mark.parametrize("n,iters", [(20, 60), (40, 40), (300, 24), (1024, 8)])
+def test_one_wave_and_two_wave_tree_kernels_agree(oracle, monkeypatch, n, iters):
+    """k_expand runs on two waves per slot by default -- a growth wave (k_expand<true, 1>) or, where the tower launch grew the
+    tree, a commit wave (<true, 2>) beside the main wave; DIEE_EXPAND2=0 / DIEE_EXPAND2C=0 bring the one-wave kernels back
+    (<false, 0> / <true, 0>).  All four combinations: the same visit distributions and counters, from the tail's cluster
+    launches (20, 40 roots) through the compacted pair tower (300) to the full chip (1024)"""
+    import diee_amd
+    walk = oracle.random_walk_states(83, 60)
+    late = walk[walk["off"].max(axis=1) >= 11][:n // 4]
+    rest = walk[100:100 + 3 * (n - len(late)):3]
+    states = np.concatenate([late, rest])[:n]
+    assert len(states) == n
+    _, gcfg = cfgs(oracle, iters)
+    gids = np.arange(n, dtype=np.uint32) + 5; rds = np.arange(n, dtype=np.uint32) % 3
+    e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+    res = []
+    for two, two_c in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("DIEE_EXPAND2", two); monkeypatch.setenv("DIEE_EXPAND2C", two_c)
+        res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 7, gids, rds, ref_quirks=True))
+    e.close()
+    a = res[0]
+    for b in res[1:]:
+        assert a["probs"].tobytes() == b["probs"].tobytes() and (a["root_visits"] == b["root_visits"]).all()
+        assert (a["n_children"] == b["n_children"]).all()
+        for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+            assert a["stats"][key] == b["stats"][key], key
+    assert a["stats"]["terminal_hits"] > 0
