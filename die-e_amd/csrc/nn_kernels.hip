@@ -1951,7 +1951,7 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
     // does it for up to four clusters (FETCH_SIZE per launch at 4 boards: 45 MB against 181 MB; at 16: 181 against 362) and the
     // workgroups dispatched to the cluster-free XCDs are the growth blocks.  Measured per search iteration: 105.8 vs 108.4 us at 4 boards,
     // 106.4 vs 111.3 at 8, 108.1 vs 110.6 at 16 (one XCD for 4 boards: 108.1; four XCDs for 8: 107.8; profiles/r03s_cl_pack_*).
-    static const bool pack = getenv("DIEE_CL_PACK") == nullptr || atoi(getenv("DIEE_CL_PACK")) != 0;
+    const bool pack = getenv("DIEE_CL_PACK") == nullptr || atoi(getenv("DIEE_CL_PACK")) != 0;       // (per launch: the tests switch it in one process)
     int nx = !pack ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;
     if (64 * ((groups + nx - 1) / nx) > capacity) nx = 8;  // (a device with fewer CUs than the packed grid dispatches: one XCD per cluster)
     const int grid = 64 * ((groups + nx - 1) / nx);
