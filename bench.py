@@ -4,9 +4,11 @@
 One "step" = one complete self_play_parallel batch (alpha_parallel.rs:101-231): 1024 backgammon
 games per GPU played to completion with iterations=100 MCTS and a random-init 19-block ResNet
 (BASELINE.json configs[1]).  `value` = games retired by all ranks / wall time of the K timed
-steps, inputs (weights, game states) resident in HBM when the timed region starts.
+steps, inputs (weights, game states) resident in HBM when the timed region starts and the call's
+outputs -- all_memories, alpha_parallel.rs:215-230: relabelled, ordered MemoryFragments -- DELIVERED
+in host memory when it ends (`value_hbm_only`: the same batches with the records left in HBM).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--iterations I]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}] [--games G] [--iterations I]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: games are independent, so ranks are independent data-parallel workers (weak scaling,
@@ -99,7 +101,7 @@ def _omp_search(job):
     return out
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=4, games_budget_s=90.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
     `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
@@ -110,7 +112,9 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
       B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308, pool sized at main.rs:107-110):
              one search per root, one PROCESS per host core (the reference's rayon threads share no interpreter lock; Python
              threads would), batch-1 single-threaded network evaluations -- no cross-game batching, no serial section.
-    Returns the faster of the two as `value` (games/s, extrapolated with the GPU run's expansions per game)."""
+      B-games  `games` whole games played to completion (B-ref machinery; the batch is the live games, so the network
+             runs at batch <= games): reported beside the extrapolation as `games_played_value`.
+    Returns the faster of B-ref / B-omp as `value` (games/s, extrapolated with the GPU run's expansions per game)."""
     import multiprocessing as mp
     cores = host_cores()
     workers = max(1, min(cores, n_roots))
@@ -173,7 +177,25 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
         "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores, "iterations_of_the_sample": it_ref,
         "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
         "what": f"one batched search over {n_roots} roots (serial C tree loops + fp32 PyTorch CPU ResNet on {cores} intra-op threads)"}
-    best = max(out["variants"], key=lambda k: out["variants"][k]["expansions_per_s"])
+    # ---- B-games: whole games, not an extrapolation -- `games` games of self_play_parallel played to completion at the
+    # full iteration count by the same B-ref machinery (serial C driver + tree, the network batch on every core)
+    if games > 0:
+        t8 = calibrate(roots[:games])
+        while games > 1 and t8 * (iterations + 1) * 130 > games_budget_s:       # ~130 move-steps for the longest of a few games
+            games -= 1
+            t8 = calibrate(roots[:games])
+        cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+        t = time.time()
+        sp = orc.self_play_parallel(1, games, cfg, 1.25, seed, orc.make_eval(fn, 1352), None, ref_quirks=1)
+        dt = time.time() - t
+        out["variants"]["B-games"] = {
+            "games_per_s": games / dt, "games": games, "seconds": dt, "threads": cores, "iterations": iterations,
+            "expansions_per_s": sp["stats"]["expansions"] / dt, "move_steps": int(sp["steps"]), "fragments": int(len(sp["outcome"])),
+            "plies_per_game": float(sp["plies"].mean()),
+            "what": f"{games} games of self_play_parallel played to completion (oracle driver + tree in C on one thread, fp32 PyTorch CPU "
+                    f"ResNet on {cores} intra-op threads, network batch = live games <= {games}): a measured games/s, small-batch"}
+        out["games_played_value"] = games / dt
+    best = max((k for k in out["variants"] if k != "B-games"), key=lambda k: out["variants"][k]["expansions_per_s"])
     eps = out["variants"][best]["expansions_per_s"]
     out["expansions_per_s"] = eps
     out["value"] = eps / exp_per_game if exp_per_game else None
@@ -186,12 +208,12 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0):
     return out
 
 
-def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=240):
+def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=420, games=4):
     """cpu_baseline in a child process (its own thread-pool settings; killed by PID after timeout_s): the baseline is a
     report and must never hang the bench line"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--iterations", str(iterations),
-           "--seed", str(seed), "--exp-per-game", repr(float(exp_per_game))]
+           "--seed", str(seed), "--exp-per-game", repr(float(exp_per_game)), "--cpu-games", str(games)]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -203,25 +225,85 @@ def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=240):
     return {"value": None, "unit": "games/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {why}"}
 
 
+def learn_loop_leg(eng, games, iterations, timeout_s=3000):
+    """BASELINE configs[4] (learn_iterations=2, self_play_iterations=4, num_epochs=4, training_batch_size=256; SURVEY 8(d) item 5:
+    wall-clock per phase) in a CHILD process: the learn loop trains with PyTorch-ROCm, whose bundled HIP runtime has to
+    initialise before libdiee.so's -- this process loaded the engine first.  The parent's engine is idle meanwhile."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "learn_config5.py"), str(games), "2", str(iterations)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"failed": f"rc {p.returncode}: {p.stderr.decode()[-400:]}"}
+    except subprocess.TimeoutExpired:
+        return {"failed": f"no result within {timeout_s} s"}
+
+
+PRESETS = {   # BASELINE.json configs[] that are self-play runs (configs[0] = tic-tac-toe plumbing, configs[4] = the learn loop: --learn-loop)
+    1: dict(games=1024, iterations=100, name="configs[1]: backgammon, num_self_play_batches=1024, iterations=100, 1 GPU (the metric's own configuration)"),
+    2: dict(games=1024, iterations=400, name="configs[2]: backgammon, num_self_play_batches=8192 over 8 GPUs = 1024 per GPU, iterations=400"),
+    3: dict(games=1024, iterations=1600, name="configs[3]: backgammon deep tree, iterations=1600, simulate_round_limit=400"),
+}
+BAND_NAMES = ["1-16", "17-32", "33-64", "65-128", "129-256", "257-512", "513-928", "929-1024", ">1024"]     # DIEE_BANDS (include/diee.h)
+
+
+def pin_to_gpu_numa(torch, dev):
+    """N > 1: keep this rank's host thread (it draws the Dirichlet samples and enqueues ~300 launches per move-step) on the
+    NUMA node of its GPU.  Best effort: returns a description for the line, never fails the run."""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return f"gpu {bdf}: no NUMA node reported"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return f"gpu {bdf} on NUMA node {node}: none of its CPUs is in this process's affinity mask"
+        os.sched_setaffinity(0, allowed)
+        return f"gpu {bdf} on NUMA node {node}: pinned to {len(allowed)} of its CPUs"
+    except Exception as e:      # (containers hide sysfs entries; a box without NUMA info runs unpinned)
+        return f"not pinned ({type(e).__name__}: {e})"
+
+
 def main(argv=None, engine_factory=None):
-    """argv / engine_factory: tests/test_dist_cpu.py drives this very function on two gloo ranks with a stand-in engine
+    """argv / engine_factory: tests/test_dist_cpu.py drives this very function on gloo ranks with a stand-in engine
     (DIEE_BENCH_BACKEND=gloo: CPU tensors for the reductions, no torch.cuda call); the driver and users run it as a script."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--games", type=int, default=1024, help="num_self_play_batches per GPU")
-    ap.add_argument("--iterations", type=int, default=100)
+    ap.add_argument("--config", type=int, choices=sorted(PRESETS), default=1, help="BASELINE.json configs[] preset: 1 = 1024 games x iterations 100 "
+                    "(the metric's configuration, default), 2 = 1024 per GPU x 400, 3 = 1024 x 1600 (deep tree)")
+    ap.add_argument("--games", type=int, default=None, help="num_self_play_batches per GPU (overrides the preset)")
+    ap.add_argument("--iterations", type=int, default=None, help="MCTS iterations (overrides the preset)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-games", type=int, default=4, help="whole games the CPU baseline also plays to completion (0 = extrapolation only)")
     ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--exp-per-game", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--pipeline", type=int, default=4, help="also time K batches played side by side through diee_self_play_multi "
                     "(self_play_iterations of the learn loop; 0 = skip); reported as value_pipelined, never as value")
+    ap.add_argument("--hbm-only-steps", type=int, default=2, help="also repeat this many of the timed batches (same seeds) with the records left in HBM: "
+                    "value_hbm_only / output_delivery_ms (0 = skip)")
+    ap.add_argument("--learn-loop", action="store_true", help="also run BASELINE configs[4] (learn_iterations=2, self_play_iterations=4, num_epochs=4, "
+                    "training_batch_size=256) after the self-play legs and report its wall-clock per phase as `learn_loop` (adds minutes)")
+    ap.add_argument("--learn-games", type=int, default=None, help="num_self_play_batches of the --learn-loop run (default: --games)")
     args = ap.parse_args(argv)
+    preset = PRESETS[args.config]
+    custom = args.games is not None or args.iterations is not None
+    if args.games is None:
+        args.games = preset["games"]
+    if args.iterations is None:
+        args.iterations = preset["iterations"]
     if args.cpu_baseline_only:                   # child of cpu_baseline_guarded: CPU only, never touches the GPU
-        print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game)))
+        print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game, games=args.cpu_games)))
         return
 
     import importlib
@@ -231,21 +313,29 @@ def main(argv=None, engine_factory=None):
     red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     dev = local_rank
+    affinity = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
         # device_count() does not initialise the GPU; a launcher may have narrowed HIP_VISIBLE_DEVICES to one GPU per rank
         ndev = torch.cuda.device_count()
+        narrowed = "HIP_VISIBLE_DEVICES" in os.environ or "ROCR_VISIBLE_DEVICES" in os.environ
+        if backend == "nccl" and world > 1 and ndev < world and not (narrowed and ndev >= 1):
+            # RCCL cannot put two ranks on one device, and a rank that silently shares a GPU would halve the figure it reports
+            raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s): launch with --nproc-per-node <= the GPUs of the node "
+                             "(or one HIP_VISIBLE_DEVICES entry per rank)")
         if backend == "nccl" or ndev > 0:          # (gloo on a GPU box: ranks that share a device, tests/test_dist_gpu.py)
             ndev = max(ndev, 1)
             dev = local_rank % ndev
-            if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+            if world > ndev and not narrowed:
                 # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
                 # which two processes on one GPU cannot promise each other
                 os.environ["DIEE_TOWER_CL"] = "none"
                 os.environ["DIEE_TOWER_PAIR"] = "0"     # (the pair tower hands over inside its launch too)
                 os.environ["DIEE_BN_COOP"] = "0"
             torch.cuda.set_device(dev)             # torch's HIP runtime initialises before libdiee.so's
+            if world > 1:
+                affinity = pin_to_gpu_numa(torch, dev)
         dist.init_process_group(backend)           # "nccl" is RCCL on ROCm
 
     import diee_amd
@@ -253,8 +343,9 @@ def main(argv=None, engine_factory=None):
     eng.load_weights(diee_amd.random_weights(0))
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     first_id = ddist.shard_first_game_id(rank, args.games)
-    # primer (not a step): pages in the code objects and sizes the HBM arenas
-    eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=False)
+    # primer (not a step): pages in the code objects, sizes the HBM arenas and pins the host blocks the records land in
+    o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=True, copy=False)
+    o.get("free", lambda: None)()
 
     def barrier():
         if dist is not None:
@@ -263,42 +354,76 @@ def main(argv=None, engine_factory=None):
                 import torch
                 torch.cuda.synchronize()
 
-    def run_step(i):
-        return eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
-                                      first_game_id=first_id, fetch=False, max_steps=args.max_steps)["stats"]
+    def run_step(i, fetch=True):
+        """one self_play_parallel call as a host binding the C ABI makes it: the call returns with the MemoryFragments in
+        engine-owned host arrays (fetch) -- looked at, handed back -- or with the records left in HBM (the HBM-only leg)"""
+        t = time.perf_counter()
+        o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
+                                   first_game_id=first_id, fetch=fetch, copy=False, max_steps=args.max_steps)
+        st = o["stats"]
+        if fetch:
+            assert len(o["outcome"]) == st["fragments"] and o["ps"].shape == (st["fragments"], 1352), "delivered records != counted records"
+            o.get("free", lambda: None)()
+        return st, time.perf_counter() - t
+
+    def add(tot, st):
+        for k, v in st.items():
+            if isinstance(v, list):
+                for b, x in enumerate(v):
+                    tot[f"{k}.{b}"] = tot.get(f"{k}.{b}", 0) + x
+            else:
+                tot[k] = tot.get(k, 0) + v
 
     for i in range(args.warmup):
         run_step(1000 + i)
     barrier()
     t0 = time.perf_counter()
-    tot = {}
+    tot, step_s = {}, []
     for i in range(args.steps):
-        st = run_step(i)                            # the call returns after the stream has drained
-        for k, v in st.items():
-            tot[k] = tot.get(k, 0) + v
+        st, ds = run_step(i)                        # the call returns after its last record has landed in host memory
+        step_s.append(ds)
+        add(tot, st)
     barrier()
     dt = time.perf_counter() - t0
+
+    # ---- the same batches with the records left in HBM (what earlier rounds timed): what delivery costs ----
+    hbm = None
+    H = min(args.hbm_only_steps, args.steps)
+    if H > 0:
+        barrier()
+        th0 = time.perf_counter()
+        hb = [run_step(i, fetch=False) for i in range(H)]
+        barrier()
+        dth = time.perf_counter() - th0
+        hbm = {"steps": H, "seconds": dth, "games": sum(st["games"] for st, _ in hb),
+               "same_seed_delta_ms": [1e3 * (step_s[i] - hb[i][1]) for i in range(H)]}
 
     # ---- second figure: the same batches, K at a time, sharing every network launch (diee_self_play_multi) ----
     pipe = None
     if args.pipeline > 1:
         K = args.pipeline
         batches = [(args.games, first_id, args.seed + 0x9E37 * i) for i in range(K)]
-        eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, max_steps=1, fetch=False)      # sizes the arenas
+        for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, max_steps=1, fetch=True, copy=False):      # sizes the arenas
+            o.get("free", lambda: None)()
         barrier()
         tp0 = time.perf_counter()
-        sts = [o["stats"] for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=False, max_steps=args.max_steps)]
+        outs = eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=True, copy=False, max_steps=args.max_steps)
+        sts = [o["stats"] for o in outs]
+        for o in outs:
+            o.get("free", lambda: None)()
         barrier()
         dtp = time.perf_counter() - tp0
         pipe = {k: sum(st[k] for st in sts) for k in ("games", "expansions", "nn_evals", "nn_rows", "plies", "fragments")}
         pipe["move_steps"] = max(st["move_steps"] for st in sts)
         pipe["tower_seconds"], pipe["tower_launches"], pipe["tower_flops"] = (sts[0][k] for k in ("tower_seconds", "tower_launches", "tower_flops"))
+        pipe["deliver_seconds"], pipe["deliver_bytes"] = sts[0].get("deliver_seconds", 0.0), sts[0].get("deliver_bytes", 0)
 
     keys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "move_steps", "children", "selections", "depth_sum",
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
             "full_seconds", "full_launches", "full_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
-            "fragments", "illegal_decodes"]
+            "fragments", "illegal_decodes", "deliver_seconds", "deliver_bytes"]
+    keys += [f"{n}.{b}" for n in ("band_seconds", "band_launches", "band_flops") for b in range(len(BAND_NAMES))]
     frags_per_rank = [int(tot.get("fragments", 0))]
     if dist is not None:
         # SURVEY 8(e): after a self-play batch the ranks all-gather their fragment counts (8 x u64 on a node) -- what a
@@ -306,17 +431,24 @@ def main(argv=None, engine_factory=None):
         frags_per_rank = ddist.gather_counts(dist, frags_per_rank[0], red_dev)
         dt, red = ddist.reduce_stats(dist, dt, tot, keys, red_dev)
         tot.update(red)
+        if hbm is not None:
+            hbm["seconds"], red = ddist.reduce_stats(dist, hbm["seconds"], hbm, ["games"], red_dev)
+            hbm.update(red)
         if pipe is not None:
             pkeys = ["games", "expansions", "nn_evals", "nn_rows", "plies", "fragments", "tower_seconds", "tower_launches", "tower_flops"]
             dtp, red = ddist.reduce_stats(dist, dtp, pipe, pkeys, red_dev)
             pipe.update(red)
+
+    learn = None
+    if args.learn_loop and world == 1 and engine_factory is None:
+        learn = learn_loop_leg(eng, args.learn_games or args.games, args.iterations)
 
     if rank == 0:
         games = tot["games"]
         exp_per_game = tot["expansions"] / max(games, 1)
         def pmc_traffic(name, fname=TRAFFIC_FILE):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/r03x_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
+            # (profiles/*_pmc_traffic*.json, scripts/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction), at 1024 / 32 boards
             try:
                 doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
@@ -338,6 +470,8 @@ def main(argv=None, engine_factory=None):
                 pass
             return None
 
+        sampled_total = tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"]
+
         def roof(kernel, sec, launches, flops, traffic=None, busy=None, busy_file=None):
             if not sec:
                 return None
@@ -352,15 +486,14 @@ def main(argv=None, engine_factory=None):
                     "launches_sampled": launches / world,
                     "avg_launch_us": sec / max(launches, 1) * 1e6,
                     "algorithmic_flops_per_launch": flops / max(launches, 1),
-                    "share_of_sampled_tower_time": sec / (tot["conv_seconds"] + tot["tower_seconds"] + tot["cluster_seconds"])}
+                    "share_of_sampled_tower_time": sec / sampled_total}
         # the tower of 38 3x3 convs is ~90 % of the GPU time; it runs as ONE fused launch (k_tower16: activations in LDS)
         # (k_tower16p: a board group over two workgroups, 129 ... 512 boards) while more than 128 games are alive and as ONE
         # cluster launch (k_tower_cl: 8-workgroup clusters per board group) at 128 games or fewer; the two `roofline_other` rows
         # go by band (> 256 / <= 256 boards) as in earlier rounds; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
-        # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch (33 % of the batch's
-        # kernel time; 58 % of the default run's with the pipelined leg).  Its sampled launches are timed one to one, so
-        # `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
-        # (`bench.py --no-cpu-baseline --pipeline 0`: profiles/r03x_headline_kernel_stats.csv).  `roofline_other` keeps
+        # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch.  Its sampled launches are
+        # timed one to one, so `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
+        # (`bench.py --no-cpu-baseline --pipeline 0 --hbm-only-steps 0`, profiles/).  `roofline_other` keeps
         # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
         r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
                       tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"),
@@ -380,19 +513,36 @@ def main(argv=None, engine_factory=None):
             dominant, other = ranked[0], ranked[1:]
         else:                                        # nothing was sampled (a run too short for a sample)
             dominant, other = None, []
+        e2e = tot["nn_rows"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world)
+        if dominant is not None:
+            # FIRST thing to read: the whole job against the roof -- every kernel, every launch gap, the host, the delivery of the
+            # records: network FLOPs really performed / wall time / dense bf16 peak.  `frac` below describes the dominant kernel alone.
+            dominant = dict({"end_to_end_frac": e2e}, **dominant)
+            # where a batch's network time goes as it shrinks: every sampled evaluation of this run (each 17th, HIP events on the
+            # engine's stream) binned by the boards of its launch
+            bands = []
+            for b, name in enumerate(BAND_NAMES):
+                sec, n, fl = tot.get(f"band_seconds.{b}", 0), tot.get(f"band_launches.{b}", 0), tot.get(f"band_flops.{b}", 0)
+                if n:
+                    bands.append({"boards": name, "sampled_evaluations": n / world, "share_of_network_time": sec / sampled_total,
+                                  "avg_us": sec / n * 1e6, "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS})
+            dominant["bands"] = bands
+        workload = (f"{preset['name']}: " if not custom else "") + (
+            f"backgammon self_play_parallel, num_self_play_batches={args.games} per GPU, "
+            f"iterations={args.iterations}, exploration_const=2, temperature=1.25, "
+            "simulate_round_limit=400, dirichlet 0.3/0.25, random-init 19x256 ResNet (seed 0), "
+            "ref_quirks on, records delivered to host memory inside the timed region"
+            + (f", TRUNCATED to {args.max_steps} move-steps per batch (profiling run)" if args.max_steps else ""))
         out = {
             "metric": "self-play games/sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"backgammon self_play_parallel, num_self_play_batches={args.games} per GPU, "
-                                   f"iterations={args.iterations}, exploration_const=2, temperature=1.25, "
-                                   "simulate_round_limit=400, dirichlet 0.3/0.25, random-init 19x256 ResNet (seed 0), "
-                                   "ref_quirks on" + (f", TRUNCATED to {args.max_steps} move-steps per batch (profiling run)" if args.max_steps else ""), "parallelism": f"dp{world} (independent games, no collective)"},
+            "config": {"workload": workload, "parallelism": f"dp{world} (independent games, no collective)"},
             "node_expansions_per_s": tot["expansions"] / dt,
             # nn_evals = batch rows as the reference counts them (all N slots per iteration, stale rows included);
             # nn_rows = rows the engine really evaluated (stale rows are skipped above 256 live games)
             "nn_evals_per_s": tot["nn_evals"] / dt, "nn_rows_per_s": tot["nn_rows"] / dt,
-            "mfma_fraction_end_to_end": tot["nn_rows"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "mfma_fraction_end_to_end": e2e,
             "stats": {"games": games, "plies_per_game": tot["plies"] / max(games, 1), "move_steps": tot["move_steps"],
                       "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
@@ -400,24 +550,41 @@ def main(argv=None, engine_factory=None):
             "roofline": dominant, "roofline_other": other,
             "fragments_per_rank": frags_per_rank,    # all_gather of the per-rank record counts; the records stay on their rank
         }
+        # what the delivery of the records costs: the same batches (same seeds) with the records left in HBM
+        out["output_delivery"] = {
+            "bytes_per_step": tot.get("deliver_bytes", 0) / max(args.steps, 1) / world,
+            "host_ms_per_step_in_delivery_calls": 1e3 * tot.get("deliver_seconds", 0) / max(args.steps, 1) / world,
+            "what": "every move-step's flushed games are relabelled / ordered / gathered on the device (k_deliver_scan, k_deliver_copy) and copied "
+                    "into page-locked host arrays on a second stream while the next move-steps search; host_ms = enqueueing those + the wait for "
+                    "the last copy after the last move-step"}
+        if hbm is not None:
+            out["value_hbm_only"] = hbm["games"] / hbm["seconds"]
+            out["output_delivery_ms"] = sum(hbm["same_seed_delta_ms"]) / len(hbm["same_seed_delta_ms"])
+            out["output_delivery"].update(hbm_only_steps=hbm["steps"], same_seed_delta_ms=hbm["same_seed_delta_ms"],
+                                          delivered_over_hbm_only=(hbm["seconds"] / hbm["steps"]) / (sum(step_s[:hbm["steps"]]) / hbm["steps"]))
+        if affinity is not None:
+            out["host_affinity_rank0"] = affinity
         out["scale_note"] = ("N>1 never run on hardware by the build (gpurun boxes have one GPU); ranks are independent workers (no data-path collective): expected weak scaling = N x the 1-GPU value; "
-                                 "this code path has run under torch.distributed.run at world size 1 on RCCL (tests/test_dist_gpu.py) and at world size 2 on gloo (tests/test_dist_cpu.py)")
+                                 "this code path has run under torch.distributed.run at world size 1 on RCCL (tests/test_dist_gpu.py) and at world sizes 2 and 8 on gloo (tests/test_dist_cpu.py)")
         if pipe is not None:
             # NOT the headline: `value` above stays one self_play_parallel call per step, as the reference issues them
             out["value_pipelined"] = pipe["games"] / dtp
             out["pipelined"] = {
                 "what": f"{args.pipeline} self_play_parallel batches of {args.games} games per GPU played side by side in one "
                         "diee_self_play_multi call (the learn loop's self_play_iterations, alpha_parallel.rs:49-62): all "
-                        "batches share every network launch, each keeps its own seed / Dirichlet stream / Q14 bookkeeping",
+                        "batches share every network launch, each keeps its own seed / Dirichlet stream / Q14 bookkeeping; records delivered",
                 "batches": args.pipeline, "seconds": dtp, "games": pipe["games"], "move_steps": pipe["move_steps"],
                 "node_expansions_per_s": pipe["expansions"] / dtp, "nn_evals_per_s": pipe["nn_evals"] / dtp,
                 "nn_rows_per_s": pipe["nn_rows"] / dtp,
                 "mfma_fraction_end_to_end": pipe["nn_rows"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
                 "fused_tower_tflops": (pipe["tower_flops"] / pipe["tower_seconds"] / 1e12) if pipe["tower_seconds"] else None,
                 "fused_tower_avg_launch_us": (pipe["tower_seconds"] / max(pipe["tower_launches"], 1) * 1e6) if pipe["tower_seconds"] else None,
+                "deliver_bytes": pipe["deliver_bytes"], "host_ms_in_delivery_calls": 1e3 * pipe["deliver_seconds"],
             }
+        if learn is not None:
+            out["learn_loop"] = learn
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_guarded(args.iterations, args.seed, exp_per_game)
+            out["cpu_baseline"] = cpu_baseline_guarded(args.iterations, args.seed, exp_per_game, games=args.cpu_games)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

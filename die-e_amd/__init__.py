@@ -29,6 +29,7 @@ NO_MOVE = -2
 GAME_TTT, GAME_BACKGAMMON = 0, 1
 FLAG_REF_QUIRKS = 1
 FLAG_INVARIANT_NN = 2
+BAND_BOUNDS = (16, 32, 64, 128, 256, 512, 928, 1024)     # DIEE_BANDS: upper bounds of Stats.band_* (the ninth band is everything above)
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_WEIGHTS, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
 
@@ -83,10 +84,12 @@ class Stats(C.Structure):
                    ("tower_seconds", C.c_double), ("tower_launches", C.c_uint64), ("tower_flops", C.c_double),
                    ("cluster_seconds", C.c_double), ("cluster_launches", C.c_uint64), ("cluster_flops", C.c_double),
                    ("nn_rows", C.c_uint64),
-                   ("full_seconds", C.c_double), ("full_launches", C.c_uint64), ("full_flops", C.c_double)])
+                   ("full_seconds", C.c_double), ("full_launches", C.c_uint64), ("full_flops", C.c_double),
+                   ("deliver_seconds", C.c_double), ("deliver_bytes", C.c_uint64),
+                   ("band_seconds", C.c_double * 9), ("band_launches", C.c_uint64 * 9), ("band_flops", C.c_double * 9)])
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith("band_") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class Fragments(C.Structure):
@@ -328,29 +331,45 @@ class Engine:
                                           probs.ctypes.data, nch.ctypes.data, rv.ctypes.data, C.byref(st)))
         return {"probs": probs, "n_children": nch, "root_visits": rv, "stats": st.as_dict()}
 
-    def _take_fragments(self, fr, out):
+    def _take_fragments(self, fr, out, copy=True):
+        """diee_fragments -> numpy.  copy=True: arrays of their own, the engine's blocks go back at once.  copy=False: views of
+        the engine-owned (page-locked) arrays, valid until out["free"]() -- what a host that binds the C ABI works with."""
         n = fr.n
-        out["outcome"] = np.ctypeslib.as_array(fr.outcome, shape=(n,)).copy() if n else np.zeros(0, np.int8)
         A, P = self.n_actions, self.n_planes
-        out["ps"] = np.ctypeslib.as_array(fr.ps, shape=(n, A)).copy() if n else np.zeros((0, A), np.float32)
-        out["state"] = np.ctypeslib.as_array(fr.state, shape=(n, P)).copy() if n else np.zeros((0, P), np.float32)
-        out["game"] = np.ctypeslib.as_array(fr.game, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
-        self._L.diee_free_fragments(C.byref(fr))
+        view = {"outcome": np.ctypeslib.as_array(fr.outcome, shape=(n,)) if n else np.zeros(0, np.int8),
+                "ps": np.ctypeslib.as_array(fr.ps, shape=(n, A)) if n else np.zeros((0, A), np.float32),
+                "state": np.ctypeslib.as_array(fr.state, shape=(n, P)) if n else np.zeros((0, P), np.float32),
+                "game": np.ctypeslib.as_array(fr.game, shape=(n,)) if n else np.zeros(0, np.uint32)}
+        if copy:
+            out.update({k: v.copy() for k, v in view.items()})
+            self._L.diee_free_fragments(C.byref(fr))
+            return
+        out.update(view)
+        L = self._L
+
+        def free(fr=fr, done=[False]):
+            if not done[0]:
+                done[0] = True
+                for k in view:
+                    out.pop(k, None)
+                L.diee_free_fragments(C.byref(fr))
+        out["free"] = free
 
     def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0xD1EE0001, ref_quirks=True,
-                           first_game_id=0, max_steps=0, fetch=True, invariant_nn=False):
-        """AlphaZero::self_play_parallel -> dict(outcome, ps, state, game, stats)"""
+                           first_game_id=0, max_steps=0, fetch=True, invariant_nn=False, copy=True):
+        """AlphaZero::self_play_parallel -> dict(outcome, ps, state, game, stats).  fetch=False: results stay in HBM (timing
+        aid); copy=False: see _take_fragments"""
         fr = Fragments(); st = Stats()
         flags = (FLAG_REF_QUIRKS if ref_quirks else 0) | (FLAG_INVARIANT_NN if invariant_nn else 0)
         self._chk(self._L.diee_self_play(self._h, n_games, first_game_id, C.byref(cfg), temperature, seed,
                                          flags, max_steps, C.byref(fr) if fetch else None, C.byref(st)))
         out = {"stats": st.as_dict()}
         if fetch:
-            self._take_fragments(fr, out)
+            self._take_fragments(fr, out, copy)
         return out
 
     def self_play_multi(self, batches, cfg, temperature=1.25, ref_quirks=True, max_steps=0, fetch=True,
-                        invariant_nn=False):
+                        invariant_nn=False, copy=True):
         """K self_play_parallel calls played side by side (diee_self_play_multi): batches = [(n_games,
         first_game_id, seed), ...] -> list of per-batch dicts like self_play_parallel's"""
         K = len(batches)
@@ -363,7 +382,9 @@ class Engine:
         for k in range(K):
             out = {"stats": sts[k].as_dict()}
             if fetch:
-                self._take_fragments(frs[k], out)
+                self._take_fragments(frs[k], out, copy)
+                if not copy:
+                    out["_keep"] = frs            # (the array of diee_fragments the free closures point into)
             outs.append(out)
         return outs
 

@@ -145,6 +145,7 @@ diee_status diee_probe_dice(diee_ctx* c, uint64_t seed, const uint32_t* ctr, uin
 namespace diee {
 size_t weights_count_bg();
 void random_weights_bg(uint64_t seed, float* blob);
+bool pinned_release(void* p);   // search_host.cpp: back to the pool of page-locked blocks; false = not one of its blocks
 }
 
 extern "C" {
@@ -328,7 +329,9 @@ diee_status diee_train_colsum(const void* a, float* out, int rows, float* scratc
 
 void diee_free_fragments(diee_fragments* f) {
     if (!f) return;
-    free(f->outcome); free(f->ps); free(f->state); free(f->game);
+    // the backgammon engine hands out page-locked blocks of its pool (search_host.cpp), the tic-tac-toe host path malloc'ed ones
+    void* ps[4] = {f->outcome, f->ps, f->state, f->game};
+    for (void* p : ps) if (!diee::pinned_release(p)) free(p);
     memset(f, 0, sizeof *f);
 }
 

@@ -99,7 +99,10 @@ void launch_init_games(hipStream_t st, const Games& Gm, const Segs& G, uint32_t 
 void launch_gather_roots(hipStream_t st, const Games& Gm, const Slots& S, const Segs& G, uint32_t n_live);
 void launch_play_move(hipStream_t st, const Tree& T, const Games& Gm, const Segs& G, uint32_t n_live, uint32_t step, const PlayParams& P);
 void launch_compact_live(hipStream_t st, const Games& Gm, uint32_t n_live, uint32_t n_segs, uint32_t* n_live_out);
-void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes);
+// output delivery of a move-step: the step's flushes in the reference's order (summary: DeliverSummary), then ranges of their rows
+void launch_deliver_scan(hipStream_t st, const Games& Gm, const Segs& G, uint32_t n_live, uint32_t step, DeliverEvent* ev, uint32_t* summary);
+void launch_deliver_copy(hipStream_t st, const Games& Gm, const Segs& G, const DeliverEvent* ev, uint32_t n_ev, uint32_t r0, uint32_t r1,
+                         const DeliverOut& out);
 constexpr uint32_t kRootIteration = 0xFFFFFFFFu;
 constexpr uint32_t kNoNextIteration = 0xFFFFFFFEu;
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "bg_device.h"
@@ -904,14 +905,86 @@ __global__ __launch_bounds__(1024) void k_compact_live(Games Gm, uint32_t n_live
     if (tid < (int)n_segs) n_live_out[1 + tid] = per_seg[tid];
 }
 
-// gather fragments into the output order the host computed: src = g*frag_cap + r
-__global__ void k_gather_frags(Games Gm, const uint32_t* __restrict__ src, uint32_t n, float* __restrict__ ps,
-                               float* __restrict__ planes) {
-    const uint32_t i = blockIdx.x;
-    if (i >= n) return;
-    const size_t s = src[i];
-    for (int a = threadIdx.x; a < 1352; a += blockDim.x) ps[(size_t)i * 1352 + a] = Gm.frag_ps[s * 1352 + a];
-    for (int t = threadIdx.x; t < 144; t += blockDim.x) planes[(size_t)i * 144 + t] = Gm.frag_planes[s * 144 + t];
+// ---- output delivery (alpha_parallel.rs:172-180, :215-223: `all_memories.append(...)` in the step a game is removed) ----
+// One block lists the flushes of this move-step in the live list's order (ascending game, hence batch-major; the round-limit
+// flush of a game before its win flush) and gives each the row it starts at in its batch's output of the step.  Runs behind
+// k_play_move, before k_compact_live drops the removed games from the list.  summary: DeliverSummary.
+__global__ __launch_bounds__(1024) void k_deliver_scan(Games Gm, Segs G, uint32_t n_live, uint32_t step, DeliverEvent* __restrict__ ev,
+                                                       uint32_t* __restrict__ summary) {
+    __shared__ uint32_t wrow[16], wev[16];
+    __shared__ uint32_t carry_rows, carry_ev;
+    __shared__ uint32_t seg_base[kMaxSegments], seg_rows[kMaxSegments], seg_ev0[kMaxSegments], seg_nev[kMaxSegments];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_rows = 0; carry_ev = 0; }
+    if (tid < (int)kMaxSegments) { seg_base[tid] = 0; seg_rows[tid] = 0; seg_ev0[tid] = kNone; seg_nev[tid] = 0; }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_live; c0 += 1024) {
+        const uint32_t i = c0 + tid;
+        uint32_t g = 0, seg = 0, ca = 0, cb = 0;
+        if (i < n_live) {
+            g = Gm.live[i]; seg = Gm.seg[g];
+            const uint32_t a = Gm.ev_a_count[g], b = Gm.ev_b_count[g];
+            if (a != kNone && Gm.ev_a_step[g] == step) ca = a;
+            if (b != kNone && Gm.ev_b_step[g] == step) cb = b;
+        }
+        const uint32_t nr = ca + cb, ne = (ca ? 1u : 0u) + (cb ? 1u : 0u);
+        uint32_t pr = nr, pe = ne;                              // inclusive scans inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t xr = __shfl_up(pr, d, 64), xe = __shfl_up(pe, d, 64);
+            if (lane >= d) { pr += xr; pe += xe; }
+        }
+        if (lane == 63) { wrow[wave] = pr; wev[wave] = pe; }
+        __syncthreads();
+        uint32_t off_r = carry_rows, off_e = carry_ev;
+        for (int w = 0; w < wave; ++w) { off_r += wrow[w]; off_e += wev[w]; }
+        const uint32_t row0 = off_r + pr - nr;                  // rows delivered by the slots before this one (all batches)
+        uint32_t e = off_e + pe - ne;
+        if (i < n_live && i == G.first_slot[seg]) seg_base[seg] = row0;
+        if (ca) { ev[e] = DeliverEvent{g, ca, row0, seg}; ++e; }
+        if (cb) ev[e] = DeliverEvent{g, 0x80000000u | cb, row0 + ca, seg};
+        __syncthreads();
+        if (tid == 0) { uint32_t tr = 0, te = 0; for (int w = 0; w < 16; ++w) { tr += wrow[w]; te += wev[w]; } carry_rows += tr; carry_ev += te; }
+        __syncthreads();
+    }
+    const uint32_t n_ev = carry_ev;
+    for (uint32_t e = tid; e < n_ev; e += 1024) {               // rows relative to the batch's first this step
+        DeliverEvent d = ev[e];
+        d.row0 -= seg_base[d.seg];
+        ev[e] = d;
+        atomicAdd(&seg_rows[d.seg], d.kind_count & 0x7FFFFFFFu);
+        atomicMin(&seg_ev0[d.seg], e);
+        atomicAdd(&seg_nev[d.seg], 1u);
+    }
+    __syncthreads();
+    if (tid < (int)G.n) {
+        summary[DeliverSummary::rows(G.n, tid)] = seg_rows[tid];
+        summary[DeliverSummary::ev0(G.n, tid)] = seg_nev[tid] ? seg_ev0[tid] : 0u;
+        summary[DeliverSummary::nev(G.n, tid)] = seg_nev[tid];
+    }
+}
+
+// rows [r0, r1) of one batch's output of the step -> staging rows [0, r1 - r0): ps and planes as the game recorded them,
+// outcome relabelled (:216-217: +1 where the fragment's mover won, -1 where the opponent did; 0 for a round-limit flush),
+// the originating game id.  ev = the batch's n_ev events (ascending row0).
+__global__ __launch_bounds__(256) void k_deliver_copy(Games Gm, Segs G, const DeliverEvent* __restrict__ ev, uint32_t n_ev, uint32_t r0,
+                                                      uint32_t r1, DeliverOut out) {
+    for (uint32_t r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
+        uint32_t lo = 0, hi = n_ev;                             // last event with row0 <= r
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ev[mid].row0 <= r) lo = mid; else hi = mid; }
+        const DeliverEvent d = ev[lo];
+        const uint32_t fr = r - d.row0;
+        const size_t s = (size_t)d.g * Gm.frag_cap + fr, o = (size_t)(r - r0);
+        for (int a = threadIdx.x; a < 1352 / 4; a += 256)
+            reinterpret_cast<float4*>(out.ps + o * 1352)[a] = reinterpret_cast<const float4*>(Gm.frag_ps + s * 1352)[a];
+        if (threadIdx.x < 144 / 4)
+            reinterpret_cast<float4*>(out.planes + o * 144)[threadIdx.x] = reinterpret_cast<const float4*>(Gm.frag_planes + s * 144)[threadIdx.x];
+        if (threadIdx.x == 0) {
+            const int pl = Gm.frag_player[s], w = Gm.winner[d.g];
+            out.outcome[o] = (d.kind_count >> 31) == 0 ? (int8_t)0 : (int8_t)(w == pl ? 1 : (w == -pl ? -1 : 0));
+            out.game[o] = G.first_id[d.seg] + (d.g - G.game0[d.seg]);
+        }
+    }
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
@@ -964,9 +1037,13 @@ void launch_play_move(hipStream_t st, const Tree& T, const Games& Gm, const Segs
 void launch_compact_live(hipStream_t st, const Games& Gm, uint32_t n_live, uint32_t n_segs, uint32_t* n_live_out) {
     hipLaunchKernelGGL(k_compact_live, dim3(1), dim3(1024), 0, st, Gm, n_live, n_segs, n_live_out);
 }
-void launch_gather_frags(hipStream_t st, const Games& G, const uint32_t* src, uint32_t n, float* ps, float* planes) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_gather_frags, dim3(n), dim3(256), 0, st, G, src, n, ps, planes);
+void launch_deliver_scan(hipStream_t st, const Games& Gm, const Segs& G, uint32_t n_live, uint32_t step, DeliverEvent* ev, uint32_t* summary) {
+    hipLaunchKernelGGL(k_deliver_scan, dim3(1), dim3(1024), 0, st, Gm, G, n_live, step, ev, summary);
+}
+void launch_deliver_copy(hipStream_t st, const Games& Gm, const Segs& G, const DeliverEvent* ev, uint32_t n_ev, uint32_t r0, uint32_t r1,
+                         const DeliverOut& out) {
+    if (r1 <= r0 || !n_ev) return;
+    hipLaunchKernelGGL(k_deliver_copy, dim3(std::min<uint32_t>(r1 - r0, 8192u)), dim3(256), 0, st, Gm, G, ev, n_ev, r0, r1, out);
 }
 
 }  // namespace diee

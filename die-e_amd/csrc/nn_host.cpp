@@ -312,8 +312,10 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
             if (bt->engines > 1) {
                 if (!bt->ev) HIPCHK(hipEventCreateWithFlags(&bt->ev, hipEventDisableTiming));
                 else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
+                bool took = false;                                  // (an earlier chunk of this evaluation may have grown the tree already: only ever set)
                 const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &W.grow_done);
+                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took);
+                if (took) W.grow_done = true;
                 if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
                 return ok;
             }
@@ -408,7 +410,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
         // kind 3: the whole chunk in ONE k_tower16<4,8,3> launch (geometry 8): the dominant kernel, sampled one to one
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, (kind == 1 && tgeom == 8) ? 3 : kind, -1});
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, (kind == 1 && tgeom == 8) ? 3 : kind, -1, G});
     }
     if (!heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
     return fc_done;
@@ -453,7 +455,7 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
                              W.hp.p, W.hv.p, rows->row_slot, rows->n_rows, pex, e.flags_dev.p);
         if (sample) {
             HIPCHK(hipEventRecord(ev1, st));
-            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq});     // flops per ROW: the row count is in rows_log[seq]
+            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, G});     // flops per ROW: the row count is in rows_log[seq]
         }
         fc_launch(e, W.hp.p, W.logits.p, G, rows->n_rows);
         HIPCHK(hipGetLastError());
@@ -523,6 +525,10 @@ void nn_harvest(Engine& e, diee_stats* stats) {
                 if (p.kind == 3) { W.full_seconds += ms * 1e-3; W.full_launches += p.launches; W.full_flops += p.flops; }
             } else if (p.kind == 2) { W.cluster_seconds += ms * 1e-3; W.cluster_launches += p.launches; W.cluster_flops += p.flops; }
             else { W.conv_seconds += ms * 1e-3; W.conv_launches += p.launches; W.conv_flops += p.flops; }
+            static const int bounds[DIEE_BANDS - 1] = {16, 32, 64, 128, 256, 512, 928, 1024};      // DIEE_BANDS, include/diee.h
+            int b = 0;
+            while (b < (int)DIEE_BANDS - 1 && p.boards > bounds[b]) ++b;
+            W.band_seconds[b] += ms * 1e-3; W.band_launches[b] += 1; W.band_flops[b] += p.flops;
         }
         W.free_events.push_back(p.a); W.free_events.push_back(p.b);
     }
@@ -532,6 +538,7 @@ void nn_harvest(Engine& e, diee_stats* stats) {
         stats->tower_seconds = W.tower_seconds; stats->tower_launches = W.tower_launches; stats->tower_flops = W.tower_flops;
         stats->cluster_seconds = W.cluster_seconds; stats->cluster_launches = W.cluster_launches; stats->cluster_flops = W.cluster_flops;
         stats->full_seconds = W.full_seconds; stats->full_launches = W.full_launches; stats->full_flops = W.full_flops;
+        for (int b = 0; b < (int)DIEE_BANDS; ++b) { stats->band_seconds[b] = W.band_seconds[b]; stats->band_launches[b] = W.band_launches[b]; stats->band_flops[b] = W.band_flops[b]; }
     }
 }
 void nn_reset_timing(Engine& e) {
@@ -540,6 +547,7 @@ void nn_reset_timing(Engine& e) {
     e.net->tower_seconds = 0; e.net->tower_launches = 0; e.net->tower_flops = 0;
     e.net->cluster_seconds = 0; e.net->cluster_launches = 0; e.net->cluster_flops = 0;
     e.net->full_seconds = 0; e.net->full_launches = 0; e.net->full_flops = 0;
+    for (int b = 0; b < (int)DIEE_BANDS; ++b) { e.net->band_seconds[b] = 0; e.net->band_launches[b] = 0; e.net->band_flops[b] = 0; }
 }
 
 // development probe: average device time of the tower conv kernel (modes 0 and 1) at batch G

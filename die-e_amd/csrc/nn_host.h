@@ -61,7 +61,7 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; int boards; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
                                     // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
     bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
     int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)
@@ -74,6 +74,8 @@ struct NetWeights {
     uint64_t conv_launches = 0, tower_launches = 0, cluster_launches = 0;
     double full_seconds = 0, full_flops = 0;      // the subset of the fused-tower samples that were ONE k_tower16<4,8,3> launch
     uint64_t full_launches = 0;
+    double band_seconds[DIEE_BANDS] = {}, band_flops[DIEE_BANDS] = {};   // every sample again, by the boards its launch(es) were dispatched for
+    uint64_t band_launches[DIEE_BANDS] = {};
     hipEvent_t get_event() {
         if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
         hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;

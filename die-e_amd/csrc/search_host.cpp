@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 #include "bg_device.h"
 #include "engine.h"
@@ -47,10 +50,19 @@ struct SearchBufs {
     DevBuf<int8_t> winner, frag_player;
     DevBuf<float> frag_ps, frag_planes;
     uint32_t game_cap = 0, frag_cap = 0;
-    // output staging
-    DevBuf<uint32_t> out_src;
-    DevBuf<float> out_ps, out_planes;
+    // output delivery: this step's flushes (double-buffered: the copy stream reads step s's list while step s + 1's is written),
+    // one staging buffer (the copy stream runs gather -> copies out -> next gather in order), the stream and its guards
+    DevBuf<DeliverEvent> dl_events[2];
+    DevBuf<float> dl_ps, dl_planes;
+    DevBuf<int8_t> dl_outcome;
+    DevBuf<uint32_t> dl_game;
+    uint32_t dl_rows = 0;                                      // staging rows
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};                // the copy stream is done with dl_events[i]
+    bool ev_copy_armed[2] = {false, false};
     ~SearchBufs() {
+        if (copy) (void)hipStreamDestroy(copy);
+        for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
         if (ev_main) (void)hipEventDestroy(ev_main);
         if (ev_side) (void)hipEventDestroy(ev_side);
@@ -60,6 +72,56 @@ struct SearchBufs {
 };
 
 void free_search(SearchBufs* s) { delete s; }
+
+// ---- pinned host memory for the delivered fragments ------------------------------------------------------------------
+// The arrays of a diee_fragments are page-locked so that the copies out of HBM are real asynchronous DMA (pageable
+// destinations are staged by the runtime and block the host).  Pinning costs ~0.3 ms per MB, so blocks are kept when
+// diee_free_fragments hands them back (up to DIEE_PINNED_POOL_MB, default 8192) and the next call takes them again.
+namespace {
+struct PinnedPool {
+    std::mutex m;
+    std::multimap<size_t, void*> idle;                 // size -> block
+    std::unordered_map<void*, size_t> out;             // blocks handed out
+    size_t idle_bytes = 0;
+    size_t cap_bytes() {
+        static const size_t cap = [] { const char* v = getenv("DIEE_PINNED_POOL_MB"); return (size_t)(v && *v ? strtoull(v, nullptr, 10) : 8192ull) << 20; }();
+        return cap;
+    }
+    void* acquire(size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 0xFFFFFull) & ~(size_t)0xFFFFFull;      // 1 MiB granules
+        {
+            std::lock_guard<std::mutex> lk(m);
+            auto it = idle.lower_bound(bytes);
+            if (it != idle.end() && it->first <= 2 * bytes + (64u << 20)) {
+                void* p = it->second; const size_t sz = it->first;
+                idle.erase(it); idle_bytes -= sz; out[p] = sz;
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+        std::lock_guard<std::mutex> lk(m);
+        out[p] = bytes;
+        return p;
+    }
+    size_t size_of(void* p) { std::lock_guard<std::mutex> lk(m); auto it = out.find(p); return it == out.end() ? 0 : it->second; }
+    bool release(void* p) {                              // false: not one of ours
+        if (!p) return true;
+        size_t sz;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            auto it = out.find(p);
+            if (it == out.end()) return false;
+            sz = it->second; out.erase(it);
+            if (idle_bytes + sz <= cap_bytes()) { idle.emplace(sz, p); idle_bytes += sz; return true; }
+        }
+        (void)hipHostFree(p);
+        return true;
+    }
+};
+PinnedPool& pinned_pool() { static PinnedPool* pool = new PinnedPool(); return *pool; }   // (never destroyed: the HIP runtime may be gone first)
+}  // namespace
+bool pinned_release(void* p) { return pinned_pool().release(p); }
 
 namespace {
 
@@ -105,6 +167,8 @@ void dirichlet_host(uint64_t seed, uint32_t step, float alpha, int n, float* out
 }
 namespace {
 
+constexpr uint32_t kLiveWords = 1 + 4 * kMaxSegments;        // DeliverSummary at its largest; live_host[kLiveWords] = the flag word
+
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = getenv(name);
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
@@ -133,9 +197,9 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         B.noise.ensure((size_t)kMaxSegments * 1352); B.root_value0.ensure(kMaxSegments);
         B.counters.ensure((size_t)kMaxSegments * CNT_COUNT); B.counters_bak.ensure((size_t)kMaxSegments * CNT_COUNT);
         B.seg_seed.ensure(kMaxSegments); B.seg_first_id.ensure(kMaxSegments); B.seg_game0.ensure(kMaxSegments);
-        B.seg_slots.ensure(2 * kMaxSegments); B.n_live_dev.ensure(2 + kMaxSegments);
+        B.seg_slots.ensure(2 * kMaxSegments); B.n_live_dev.ensure(kLiveWords);
         HIPCHK(hipHostMalloc((void**)&B.noise_host, sizeof(float) * 2 * kMaxSegments * 1352));
-        HIPCHK(hipHostMalloc((void**)&B.live_host, sizeof(uint32_t) * (2 + kMaxSegments)));
+        HIPCHK(hipHostMalloc((void**)&B.live_host, sizeof(uint32_t) * (kLiveWords + 1)));
     }
     if (iterations + 1 > B.iter_cap) { B.iter_flags.ensure((size_t)kMaxSegments * 2 * ((size_t)iterations + 1)); B.iter_cap = iterations + 1; }
 }
@@ -259,14 +323,14 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
 bool cluster_starved(Engine& e) {
     if (!e.net || !nn_cluster_used(e)) return false;
     SearchBufs& B = *e.search;
-    e.d2h(B.live_host + 1 + kMaxSegments, e.flags_dev.p, 1);
+    e.d2h(B.live_host + kLiveWords, e.flags_dev.p, 1);
     e.sync();
     // tests: DIEE_TEST_STARVE_AT=k treats the k-th check of the process as a starved hand-over (the fallback path has
     // no other way to be exercised on a box with one process per GPU)
     static const int starve_at = getenv("DIEE_TEST_STARVE_AT") ? atoi(getenv("DIEE_TEST_STARVE_AT")) : -1;
     static int checks = 0;
     const bool forced = ++checks == starve_at;
-    if (!(B.live_host[1 + kMaxSegments] & 4u) && !forced) return false;
+    if (!(B.live_host[kLiveWords] & 4u) && !forced) return false;
     nn_disable_cluster(e);                                            // clears the flag bit and re-arms the counters
     fprintf(stderr, "[diee] cluster tower: a workgroup hand-over starved (is another process using this GPU?); "
                     "falling back to the per-layer kernels for the rest of this process\n");
@@ -290,15 +354,27 @@ struct InvariantScope {    // DIEE_FLAG_INVARIANT_NN for the duration of one cal
     ~InvariantScope() { w->invariant = saved; }
 };
 
-struct FragBufs {          // host arrays of one diee_fragments until they are handed over
+struct FragBufs {          // host arrays of one diee_fragments until they are handed over: pinned, grown on demand
     int8_t* outcome = nullptr; float* ps = nullptr; float* state = nullptr; uint32_t* game = nullptr;
-    bool alloc(size_t n) {
-        outcome = (int8_t*)malloc(n ? n : 1); ps = (float*)malloc((n ? n : 1) * 1352 * sizeof(float));
-        state = (float*)malloc((n ? n : 1) * 144 * sizeof(float)); game = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
-        return outcome && ps && state && game;
+    size_t cap = 0, n = 0;                                     // rows
+    FragBufs() = default;
+    FragBufs(const FragBufs&) = delete;
+    FragBufs& operator=(const FragBufs&) = delete;
+    // room for `rows` rows, the first n kept.  The caller has drained the copy stream if n > 0 (copies into the old blocks).
+    void reserve(size_t rows) {
+        if (rows <= cap) return;
+        PinnedPool& P = pinned_pool();
+        const size_t nc = std::max(rows, cap + cap / 2);
+        int8_t* o = (int8_t*)P.acquire(nc); float* p = (float*)P.acquire(nc * 1352 * sizeof(float));
+        float* st = (float*)P.acquire(nc * 144 * sizeof(float)); uint32_t* g = (uint32_t*)P.acquire(nc * sizeof(uint32_t));
+        if (!o || !p || !st || !g) { P.release(o); P.release(p); P.release(st); P.release(g); throw std::bad_alloc(); }
+        if (n) { memcpy(o, outcome, n); memcpy(p, ps, n * 1352 * sizeof(float)); memcpy(st, state, n * 144 * sizeof(float)); memcpy(g, game, n * sizeof(uint32_t)); }
+        drop();
+        outcome = o; ps = p; state = st; game = g; cap = nc;
     }
-    void release(diee_fragments* f, uint32_t n) { f->n = n; f->outcome = outcome; f->ps = ps; f->state = state; f->game = game; outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; }
-    ~FragBufs() { free(outcome); free(ps); free(state); free(game); }
+    void drop() { PinnedPool& P = pinned_pool(); P.release(outcome); P.release(ps); P.release(state); P.release(game); outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; }
+    void release(diee_fragments* f) { f->n = (uint32_t)n; f->outcome = outcome; f->ps = ps; f->state = state; f->game = game; outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; cap = n = 0; }
+    ~FragBufs() { drop(); }
 };
 
 }  // namespace
@@ -400,6 +476,67 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     const uint32_t quirks = (flags & DIEE_FLAG_REF_QUIRKS) ? 1u : 0u;
     const PlayParams PP{cfg->round_limit, (float)(1.0 / (double)temperature), quirks};
 
+    // ---- output delivery (alpha_parallel.rs:215-230: the call returns all_memories) --------------------------------
+    // A game's records are final in the move-step that removes it, and the reference's order is (move-step, game, round-limit
+    // flush before win flush): the output of a batch grows by whole steps.  So each step's flushes are listed on the device
+    // (k_deliver_scan, 3 words per batch read back with the live counts), gathered + relabelled into a staging buffer and
+    // copied into pinned host arrays on a second stream while the next move-steps search; the long tail of a batch (147 of
+    // 364 move-steps with <= 32 live games) leaves nothing to wait for at the end.  outs == NULL: listed and counted only.
+    const bool deliver = outs != nullptr;
+    std::vector<FragBufs> fb(deliver ? n_batches : 0);
+    std::vector<uint64_t> frag_total(n_batches, 0);
+    for (auto& ev : B.dl_events) ev.ensure((size_t)2 * n_games);
+    B.ev_copy_armed[0] = B.ev_copy_armed[1] = false;
+    const uint32_t stage_rows = std::max<uint32_t>(env_u32("DIEE_DELIVER_STAGE_ROWS", 16384), 1);
+    double deliver_secs = 0.0;
+    uint64_t deliver_bytes = 0;
+    if (deliver) {
+        if (!B.copy) {
+            HIPCHK(hipStreamCreateWithFlags(&B.copy, hipStreamNonBlocking));
+            for (auto& e : B.ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (stage_rows > B.dl_rows) {
+            B.dl_ps.ensure((size_t)stage_rows * 1352); B.dl_planes.ensure((size_t)stage_rows * 144);
+            B.dl_outcome.ensure(stage_rows); B.dl_game.ensure(stage_rows); B.dl_rows = stage_rows;
+        }
+        // first guess: 128 records per game (a random-init game runs ~107 plies); grown when a batch outruns it
+        for (uint32_t k = 0; k < n_batches; ++k)
+            fb[k].reserve(std::min<size_t>((size_t)bt[k].n_games * frag_cap, (size_t)bt[k].n_games * env_u32("DIEE_DELIVER_ROWS_PER_GAME", 128) + 1024));
+    }
+    struct CopyDrain { hipStream_t st; ~CopyDrain() { if (st) (void)hipStreamSynchronize(st); } } drain{deliver ? B.copy : nullptr};   // (no copy may outlive its pinned target)
+    const DeliverOut stage{B.dl_ps.p, B.dl_planes.p, B.dl_outcome.p, B.dl_game.p};
+    std::vector<uint32_t> pending;                                      // DeliverSummary of the step whose records still have to go out
+    int pending_buf = 0;
+    auto deliver_pending = [&] {
+        if (pending.empty()) return;
+        const auto td = std::chrono::steady_clock::now();
+        bool sent = false;
+        for (uint32_t k = 0; k < n_batches; ++k) {
+            const uint32_t rows = pending[DeliverSummary::rows(n_batches, k)], e0 = pending[DeliverSummary::ev0(n_batches, k)],
+                           ne = pending[DeliverSummary::nev(n_batches, k)];
+            frag_total[k] += rows;
+            if (!deliver || !rows) continue;
+            FragBufs& f = fb[k];
+            if (f.n + rows > f.cap) { HIPCHK(hipStreamSynchronize(B.copy)); f.reserve(f.n + rows); }
+            for (uint32_t o = 0; o < rows; o += stage_rows) {
+                const uint32_t m = std::min(stage_rows, rows - o);
+                launch_deliver_copy(B.copy, Gm, G, B.dl_events[pending_buf].p + e0, ne, o, o + m, stage);
+                HIPCHK(hipGetLastError());
+                const size_t at = f.n + o;
+                HIPCHK(hipMemcpyAsync(f.ps + at * 1352, stage.ps, (size_t)m * 1352 * sizeof(float), hipMemcpyDeviceToHost, B.copy));
+                HIPCHK(hipMemcpyAsync(f.state + at * 144, stage.planes, (size_t)m * 144 * sizeof(float), hipMemcpyDeviceToHost, B.copy));
+                HIPCHK(hipMemcpyAsync(f.outcome + at, stage.outcome, (size_t)m, hipMemcpyDeviceToHost, B.copy));
+                HIPCHK(hipMemcpyAsync(f.game + at, stage.game, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost, B.copy));
+                deliver_bytes += (size_t)m * (1352 * 4 + 144 * 4 + 1 + 4);
+            }
+            f.n += rows;
+            sent = true;
+        }
+        if (sent) { HIPCHK(hipEventRecord(B.ev_copy[pending_buf], B.copy)); B.ev_copy_armed[pending_buf] = true; }
+        pending.clear();
+        deliver_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
+    };
+
     upload_segments(*this, bt);
     nn_reset_timing(*this);
     launch_init_games(stream, Gm, G, n_games);
@@ -420,20 +557,32 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
         launch_gather_roots(stream, Gm, S, G, n_live);
         HIPCHK(hipMemcpyAsync(B.counters_bak.p, B.counters.p, sizeof(unsigned long long) * CNT_COUNT * n_batches, hipMemcpyDeviceToDevice, stream));
         mcts_run(*this, n_live, n_batches, *cfg, buf, flags);           // :146
-        // while the GPU searches: the next move-step's Dirichlet samples (the only host arithmetic of a move-step)
+        // while the GPU searches: the next move-step's Dirichlet samples (the only host arithmetic of a move-step) and the
+        // previous move-step's records (enqueued behind this step's search so that the search never waits for the host)
         draw_noise(B, buf ^ 1, bt, step + 1, cfg->dir_alpha);
+        deliver_pending();
         if (cluster_starved(*this)) {                                   // rare: repeat this move-step's search, per-layer kernels
             HIPCHK(hipMemcpyAsync(B.counters.p, B.counters_bak.p, sizeof(unsigned long long) * CNT_COUNT * n_batches, hipMemcpyDeviceToDevice, stream));
             mcts_run(*this, n_live, n_batches, *cfg, buf, flags);
         }
         launch_play_move(stream, T, Gm, G, n_live, step, PP);           // :164-224
+        if (B.ev_copy_armed[buf]) { HIPCHK(hipStreamWaitEvent(stream, B.ev_copy[buf], 0)); B.ev_copy_armed[buf] = false; }   // (step - 2's list has been read)
+        launch_deliver_scan(stream, Gm, G, n_live, step, B.dl_events[buf].p, B.n_live_dev.p);
         launch_compact_live(stream, Gm, n_live, n_batches, B.n_live_dev.p);   // :226-228
         HIPCHK(hipGetLastError());
-        d2h(B.live_host, B.n_live_dev.p, (size_t)1 + n_batches);
+        d2h(B.live_host, B.n_live_dev.p, (size_t)1 + 4 * n_batches);
         sync();
         n_live = B.live_host[0];
         for (uint32_t k = 0; k < n_batches; ++k) live_of[k] = B.live_host[1 + k];
+        pending.assign(B.live_host, B.live_host + 1 + 4 * n_batches);
+        pending_buf = buf;
         ++step;
+    }
+    deliver_pending();
+    if (deliver) {                                                      // the last copies (one game's records, typically)
+        const auto td = std::chrono::steady_clock::now();
+        HIPCHK(hipStreamSynchronize(B.copy));
+        deliver_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     check_overflow();
@@ -441,74 +590,14 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
         nn_harvest(*this, &stats[0]);                                   // sampled tower timings: whole call, reported with batch 0
         for (uint32_t k = 0; k < n_batches; ++k) {
             read_counters(*this, k, &stats[k]);
-            stats[k].move_steps = steps_of[k]; stats[k].seconds = secs;
+            stats[k].move_steps = steps_of[k]; stats[k].seconds = secs; stats[k].fragments = frag_total[k];
         }
+        stats[0].deliver_seconds = deliver_secs; stats[0].deliver_bytes = deliver_bytes;
     } else {
         nn_harvest(*this, nullptr);
     }
-
-    // ---- outputs, per batch: order = (move-step of the flush, game), round-limit flush before win flush ----
-    std::vector<uint32_t> nfr(n_games), ea(n_games), eas(n_games), eb(n_games), ebs(n_games);
-    std::vector<int8_t> win(n_games);
-    d2h(nfr.data(), B.nfrags.p, (size_t)n_games); d2h(ea.data(), B.ev_a_count.p, (size_t)n_games);
-    d2h(eas.data(), B.ev_a_step.p, (size_t)n_games); d2h(eb.data(), B.ev_b_count.p, (size_t)n_games);
-    d2h(ebs.data(), B.ev_b_step.p, (size_t)n_games); d2h(win.data(), B.winner.p, (size_t)n_games);
-    sync();
-    struct Ev { uint32_t step, g, kind, count; };
-    std::vector<int8_t> players;
-    for (uint32_t k = 0; k < n_batches; ++k) {
-        std::vector<Ev> evs;
-        size_t total = 0;
-        for (uint32_t g = game0[k]; g < game0[k] + bt[k].n_games; ++g) {
-            if (ea[g] != 0xFFFFFFFFu) { evs.push_back({eas[g], g, 0, ea[g]}); total += ea[g]; }
-            if (eb[g] != 0xFFFFFFFFu) { evs.push_back({ebs[g], g, 1, eb[g]}); total += eb[g]; }
-        }
-        std::sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) {
-            if (a.step != b.step) return a.step < b.step;
-            if (a.g != b.g) return a.g < b.g;
-            return a.kind < b.kind;
-        });
-        if (stats) stats[k].fragments = total;
-        if (!outs || total == 0) continue;
-        if (players.empty()) {
-            players.resize((size_t)n_games * B.frag_cap);
-            d2h(players.data(), B.frag_player.p, players.size());
-            sync();
-        }
-        std::vector<uint32_t> src(total);
-        FragBufs fb;
-        if (!fb.alloc(total)) {
-            for (uint32_t j = 0; j < k; ++j) diee_free_fragments(&outs[j]);
-            throw std::bad_alloc();
-        }
-        size_t q = 0;
-        for (const Ev& ev : evs)
-            for (uint32_t r = 0; r < ev.count; ++r, ++q) {
-                const size_t si = (size_t)ev.g * B.frag_cap + r;
-                src[q] = (uint32_t)si;
-                const int pl = players[si];
-                fb.outcome[q] = ev.kind == 0 ? 0 : (win[ev.g] == pl ? 1 : (win[ev.g] == -pl ? -1 : 0));   // :216-217
-                fb.game[q] = bt[k].first_game_id + (ev.g - game0[k]);
-            }
-        // gather on the device in chunks, then copy out
-        const size_t chunk = 65536;
-        B.out_src.ensure(chunk); B.out_ps.ensure(chunk * 1352); B.out_planes.ensure(chunk * 144);
-        try {
-            for (size_t o = 0; o < total; o += chunk) {
-                const size_t m = std::min(chunk, total - o);
-                h2d(B.out_src.p, src.data() + o, m);
-                launch_gather_frags(stream, Gm, B.out_src.p, (uint32_t)m, B.out_ps.p, B.out_planes.p);
-                HIPCHK(hipGetLastError());
-                d2h(fb.ps + o * 1352, B.out_ps.p, m * 1352);
-                d2h(fb.state + o * 144, B.out_planes.p, m * 144);
-                sync();
-            }
-        } catch (...) {
-            for (uint32_t j = 0; j < k; ++j) diee_free_fragments(&outs[j]);
-            throw;
-        }
-        fb.release(&outs[k], (uint32_t)total);
-    }
+    if (deliver)
+        for (uint32_t k = 0; k < n_batches; ++k) fb[k].release(&outs[k]);
 }
 
 }  // namespace diee

@@ -97,6 +97,20 @@ struct Games {
     unsigned long long* counters;
 };
 
+// Output delivery of one move-step (alpha_parallel.rs:172-180, :215-223: a game's memory joins all_memories, relabelled, in
+// the step the game is removed).  k_deliver_scan lists this step's flushes in the reference's order -- by game, round-limit
+// flush before win flush, inside each batch -- with the row each starts at in its batch's output of the step; k_deliver_copy
+// gathers a range of those rows (ps, planes, outcome, game id) into a staging buffer, which the host copies out on a second
+// stream while the next move-step searches.
+struct DeliverEvent { uint32_t g, kind_count, row0, seg; };   // kind_count = kind << 31 | rows; row0 = first row in the step's output of the batch
+struct DeliverSummary {     // indices into the per-step summary the host reads with the live counts ([1 + 4 * segs] words)
+    static constexpr uint32_t kLive = 0;                      // [0] games alive, [1 + b] alive in batch b   (k_compact_live)
+    static __host__ __device__ uint32_t rows(uint32_t segs, uint32_t b) { return 1 + segs + b; }       // rows batch b delivers this step
+    static __host__ __device__ uint32_t ev0(uint32_t segs, uint32_t b) { return 1 + 2 * segs + b; }    // its first event
+    static __host__ __device__ uint32_t nev(uint32_t segs, uint32_t b) { return 1 + 3 * segs + b; }    // its events
+};
+struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; };    // staging, row-major
+
 struct SearchParams {
     float dir_eps;
     uint32_t quirks;

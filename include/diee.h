@@ -37,6 +37,7 @@ extern "C" {
 #define DIEE_GAME_BACKGAMMON 1
 #define DIEE_TTT_ACTIONS 9u     /* TicTacToe::ACTION_SPACE_SIZE, src/tictactoe/mod.rs:20     */
 #define DIEE_TTT_PLANES  27u    /* 3 x 3 x 3, mod.rs:83-94                                   */
+#define DIEE_BANDS 9u           /* live-game bands of diee_stats.band_*: <= 16, 32, 64, 128, 256, 512, 928, 1024, above */
 
 typedef enum {
     DIEE_OK = 0,
@@ -103,7 +104,7 @@ typedef struct {
     uint64_t illegal_decodes;  /* alpha_parallel.rs:204 self-check failures (counted)      */
     uint64_t max_children;
     uint64_t fragments;
-    double   seconds;          /* wall clock of the call, inputs resident                  */
+    double   seconds;          /* wall clock of the call, inputs resident, outputs delivered */
     double   nn_seconds;       /* HIP-event time of the ResNet kernels                     */
     double   conv_seconds;     /* HIP-event time of sampled per-layer tower conv launches   */
     uint64_t conv_launches;    /* sampled launches of k_conv3x3 / k_conv3x3_sk (tower)      */
@@ -119,9 +120,20 @@ typedef struct {
     double   full_seconds;     /* the subset of the tower_* samples that were exactly ONE k_tower16<4,8,3> launch (929 ... 1024   */
     uint64_t full_launches;    /* boards, or whole multiples of 1024): comparable one to one with that kernel's row in a          */
     double   full_flops;       /* rocprofv3 --kernel-trace --stats summary                                                        */
+    double   deliver_seconds;  /* host wall clock the call spent on output delivery: enqueueing each move-step's gather + copies    */
+                               /* on the copy stream, plus the wait for the last of them after the last move-step (batch 0 only)    */
+    uint64_t deliver_bytes;    /* bytes copied into the diee_fragments arrays, all batches of the call (batch 0 only)               */
+    /* the same sampled network evaluations (every kernel family) binned by the number of live games the evaluation was dispatched
+     * for -- upper bounds DIEE_BAND_BOUNDS, the last band is everything above one pass of the chip: where a batch's time goes as
+     * it shrinks.  seconds = HIP-event time of the tower part of the evaluation, flops = its 38 layers' algorithmic FLOPs */
+    double   band_seconds[9];
+    uint64_t band_launches[9]; /* sampled evaluations                                                                              */
+    double   band_flops[9];
 } diee_stats;
 
-/* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine */
+/* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine (page-locked: every move-step's
+ * records are copied out of HBM while the following move-steps search; `seconds` includes the last copy).  Rows are in the
+ * reference's order: by the move-step that removed the game, then by game, a round-limit flush before a win flush. */
 typedef struct {
     uint32_t  n;
     int8_t*   outcome;         /* [n]        +1 / -1 / 0                                   */

@@ -132,15 +132,19 @@ class _StubEngine:
         st.update(games=n, plies=int(out["plies"].sum()), move_steps=out["steps"], fragments=len(out["outcome"]), nn_rows=out["stats"]["nn_evals"])
         return st
 
-    def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0, ref_quirks=True, first_game_id=0, max_steps=0, fetch=True, invariant_nn=False):
+    def self_play_parallel(self, n_games, cfg, temperature=1.25, seed=0, ref_quirks=True, first_game_id=0, max_steps=0, fetch=True, invariant_nn=False,
+                           copy=True):
         from oracle import oracle as orc
         ocfg = orc.MctsCfg(iterations=cfg.iterations, c=cfg.c, round_limit=cfg.round_limit, dir_alpha=cfg.dir_alpha, dir_eps=cfg.dir_eps)
         out = orc.self_play_parallel(1, n_games, ocfg, temperature, seed, orc.hash_eval_fn(), orc.game(1), ref_quirks=1 if ref_quirks else 0,
                                      first_game_id=first_game_id, max_steps=max_steps)
-        return {"stats": self._stats(out, n_games if not max_steps else int((out["winners"] != 0).sum()))}
+        res = {"stats": self._stats(out, n_games if not max_steps else int((out["winners"] != 0).sum()))}
+        if fetch:                      # (the records, as the engine hands them over; nothing to free on this side)
+            res.update({k: out[k] for k in ("outcome", "ps", "state", "game")})
+        return res
 
-    def self_play_multi(self, batches, cfg, temperature=1.25, ref_quirks=True, max_steps=0, fetch=True, invariant_nn=False):
-        return [self.self_play_parallel(n, cfg, temperature, seed, ref_quirks, first, max_steps) for n, first, seed in batches]
+    def self_play_multi(self, batches, cfg, temperature=1.25, ref_quirks=True, max_steps=0, fetch=True, invariant_nn=False, copy=True):
+        return [self.self_play_parallel(n, cfg, temperature, seed, ref_quirks, first, max_steps, fetch) for n, first, seed in batches]
 
 
 def _bench_worker(rank, world, port, q):
