@@ -11,6 +11,7 @@ namespace diee {
 void free_net(NetWeights*);
 void cluster_baton_register(int device, int delta);
 void nn_reset_cluster(Engine& e);
+void nn_disable_cluster(Engine& e);
 void free_search(SearchBufs*);
 
 Engine::Engine(int dev) : device(dev) {
@@ -38,8 +39,13 @@ void Engine::check_overflow() {
     if (f) {
         HIPCHK(hipMemsetAsync(flags_dev.p, 0, sizeof(uint32_t), stream));
         sync();
-        if (f & 4u) nn_reset_cluster(*this);                // the hand-over counters are in an unknown state: re-arm them
-        if (f & 4u) throw EngineError(DIEE_ERR_HIP, "cluster tower: a workgroup handshake timed out (grid not co-resident?); set DIEE_TOWER_CL=none");
+        if (f & 4u) {
+            // a hand-over inside the cluster tower OR the pair tower (same flag bit) timed out: both are dropped for the rest of the
+            // process (as the search paths do, cluster_starved), so the next call does not spin to the same timeout again
+            nn_disable_cluster(*this);                      // also re-arms the hand-over counters
+            throw EngineError(DIEE_ERR_HIP, "cluster / pair tower: a workgroup hand-over timed out (grid not co-resident: another process on this GPU?); "
+                                            "both are now off for this process -- set DIEE_TOWER_CL=none DIEE_TOWER_PAIR=0 to start without them");
+        }
         throw EngineError(DIEE_ERR_CAPACITY, "device capacity overflow (sequence table / tree arena), flag=" + std::to_string(f));
     }
 }

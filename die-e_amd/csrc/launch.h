@@ -24,6 +24,7 @@ struct GrowReq { Tree T; Slots S; Segs G; uint32_t n, it; };
 
 // nn_kernels.hip
 void nn_setup_kernels();
+void nn_refresh_env();             // re-reads the per-launch development switches (DIEE_CL_PACK): once per search / API call, never beside a launch
 void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geometry (development)
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
@@ -73,6 +74,7 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
 // of zeroed device memory, `err` gets bit 2 set if a hand-over timed out.  false = too many boards.
 bool launch_tower_pair(hipStream_t st, int boards_per_pair /* 4 or 2 */, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                        const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err);
+bool tower_pair_device_ok(int device);     // 8 XCDs x >= 32 CUs: the pair's co-placement (blockIdx & 7) and co-residency (<= 256 workgroups) hold
 size_t tower_pair_exchange_bytes();
 int tower_pair_max_boards(int boards_per_pair);
 void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, const float* wv, float* policy,
@@ -81,8 +83,9 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 // mcts_kernels.hip
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks);
+struct ExpandVariant { bool two = true, two_c = true; };    // DIEE_EXPAND2 / DIEE_EXPAND2C, read by the caller once per search
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                   uint32_t next_it, float c, bool pre_grown = false);   // next_it: iteration to select for afterwards, kNoNextIteration = none;
+                   uint32_t next_it, float c, bool pre_grown = false, ExpandVariant v = ExpandVariant{});   // next_it: iteration to select for afterwards, kNoNextIteration = none;
                                                                          // pre_grown: launch_grow(it) created the children already
 // the network-independent half of expansion `it` (legal plays, child states): runs beside the network evaluation on another stream
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);

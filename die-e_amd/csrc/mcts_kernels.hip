@@ -995,15 +995,13 @@ void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
     hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, G, n, it, c, quirks);
 }
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                   uint32_t next_it, float c, bool pre_grown) {
-    // DIEE_EXPAND2=0: one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
-    // DIEE_EXPAND2C=0: children grown by the tower launch are committed by the one wave that does everything else too
-    // (read per launch: the tests switch them inside one process; two getenv calls beside a kernel launch)
-    const bool two = getenv("DIEE_EXPAND2") == nullptr || atoi(getenv("DIEE_EXPAND2")) != 0;
-    const bool two_c = getenv("DIEE_EXPAND2C") == nullptr || atoi(getenv("DIEE_EXPAND2C")) != 0;
-    if (pre_grown && two_c) hipLaunchKernelGGL((k_expand<true, 2>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
+                   uint32_t next_it, float c, bool pre_grown, ExpandVariant v) {
+    // v.two = false (DIEE_EXPAND2=0): one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
+    // v.two_c = false (DIEE_EXPAND2C=0): children grown by the tower launch are committed by the one wave that does everything else too
+    // (the caller reads the switches once per search: no getenv beside a kernel launch)
+    if (pre_grown && v.two_c) hipLaunchKernelGGL((k_expand<true, 2>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
     else if (pre_grown) hipLaunchKernelGGL((k_expand<true, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
-    else if (two) hipLaunchKernelGGL((k_expand<true, 1>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
+    else if (v.two) hipLaunchKernelGGL((k_expand<true, 1>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
     else hipLaunchKernelGGL((k_expand<false, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
 }
 void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {

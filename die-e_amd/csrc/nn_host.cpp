@@ -149,6 +149,13 @@ void Engine::load_weights(const float* blob, size_t n) {
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
     if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
     if (const char* v = getenv("DIEE_TOWER_PAIR")) net->pair_tower = atoi(v) != 0;
+    if (net->pair_tower && !tower_pair_device_ok(device)) {
+        // both members of a pair must be resident together and -- their hand-off stores are plain: they stay in the XCD's L2 -- on
+        // ONE XCD, which the kernel gets from blockIdx & 7 under round-robin dispatch to 8 XCDs; a device or partition that
+        // is not 8 XCDs x >= 32 CUs would spin every pair launch to its timeout before the (loud) fallback
+        net->pair_tower = false;
+        fprintf(stderr, "[diee] pair tower: device %d is not 8 XCDs x 32 CUs (a partition?); using the single-workgroup geometries\n", device);
+    }
     if (!net->pair_tower) net->tower_table = {{928, 8}, {416, 6}, {256, 3}};
     if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
@@ -636,6 +643,7 @@ void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* pol
     tmp_c.ensure((size_t)n * 4);
     h2d(tmp_a.p, (const uint8_t*)states, (size_t)n * 32);
     const int se = net->sample_every; net->sample_every = 0;
+    nn_refresh_env();
     nn_forward(*this, tmp_a.p, (int)n, (float*)tmp_b.p, (float*)tmp_c.p);
     net->sample_every = se;
     d2h((uint8_t*)policy, tmp_b.p, (size_t)n * 1352 * 4);

@@ -11,6 +11,7 @@
 //     no barrier inside the K loop;
 //   * v_mfma_f32_32x32x16_bf16, 6 M-fragments x 1 N-fragment per wave: 96 accumulator registers.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <cstdio>
 #include <type_traits>
@@ -1619,7 +1620,9 @@ __global__ __launch_bounds__(256) void k_tower16p(const u32x4* __restrict__ wt, 
     char* tx = smem;
     char* th = smem + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // both members of a pair on one XCD under round-robin dispatch (speed only: the hand-off is write-through + L1-bypassing)
+    // both members of a pair on one XCD under round-robin dispatch.  With the default plain hand-off stores (DIEE_PAIR_STORE_AUX=0)
+    // this is a LIVENESS condition, not just speed: a plain store stays in the producer XCD's L2, where only a same-XCD reader's
+    // L1-bypassing load finds it; tower_pair_device_ok() keeps the pair tower off devices where blockIdx & 7 is not the XCD
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3, half = j & 1, grp = xcd + 8 * (j >> 1);
     int board0 = grp * GT;
     if (rm.mode != 0) {                                          // compacted batch: mode 3, the remainder of at most kRemSplit boards
@@ -1927,6 +1930,9 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 
 // cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
 // runs the per-layer path)
+static bool g_cl_pack = true;
+void nn_refresh_env() { const char* v = getenv("DIEE_CL_PACK"); g_cl_pack = v == nullptr || atoi(v) != 0; }
+
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd,
@@ -1951,7 +1957,7 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
     // does it for up to four clusters (FETCH_SIZE per launch at 4 boards: 45 MB against 181 MB; at 16: 181 against 362) and the
     // workgroups dispatched to the cluster-free XCDs are the growth blocks.  Measured per search iteration: 105.8 vs 108.4 us at 4 boards,
     // 106.4 vs 111.3 at 8, 108.1 vs 110.6 at 16 (one XCD for 4 boards: 108.1; four XCDs for 8: 107.8; profiles/r03s_cl_pack_*).
-    const bool pack = getenv("DIEE_CL_PACK") == nullptr || atoi(getenv("DIEE_CL_PACK")) != 0;       // (per launch: the tests switch it in one process)
+    const bool pack = g_cl_pack;                                                                    // (DIEE_CL_PACK, nn_refresh_env: once per search / API call)
     int nx = !pack ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;
     if (64 * ((groups + nx - 1) / nx) > capacity) nx = 8;  // (a device with fewer CUs than the packed grid dispatches: one XCD per cluster)
     const int grid = 64 * ((groups + nx - 1) / nx);
@@ -2048,6 +2054,14 @@ bool launch_tower_pair(hipStream_t st, int boards_per_pair, const void* wt16, co
     else if (boards_per_pair == 2) tower16p_launch<2, DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err);
     else return false;
     return true;
+}
+bool tower_pair_device_ok(int device) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return false;
+    // gfx950 in SPX mode: 256 CUs = 8 XCDs x 32; CPX / DPX partitions report 32 / 128 CUs (one / four XCDs)
+    return cus == 256 && strncmp(pr.gcnArchName, "gfx950", 6) == 0;
 }
 size_t tower_pair_exchange_bytes() { return 2 * (size_t)kPairMaxGroups * 2 * kPairHalfBytes; }
 int tower_pair_max_boards(int boards_per_pair) { return boards_per_pair * kPairMaxGroups; }

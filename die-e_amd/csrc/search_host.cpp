@@ -287,6 +287,8 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     // workgroups (GrowReq) -- no second stream, no event --, and the k_expand behind it only has the priors, the backpropagation and
     // the next descent left (16.2 -> 9.4 us on the chain between two evaluations).
     const bool cl_grow = env_u32("DIEE_CL_GROW", 1) != 0;        // (read per search: the tests switch it inside one process)
+    const ExpandVariant xv{env_u32("DIEE_EXPAND2", 1) != 0, env_u32("DIEE_EXPAND2C", 1) != 0};      // likewise, and handed down to every launch
+    nn_refresh_env();                                            // (DIEE_CL_PACK)
     GrowReq greq{T, S, G, n, 0u};
     struct GrowScope { NetWeights* w; ~GrowScope() { w->grow_req = nullptr; w->grow_done = false; } } gscope{e.net};
     auto forward = [&](uint32_t it, const NnRows* rws) {
@@ -305,13 +307,13 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     const SearchParams P{cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
     join();
-    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, split || hc.grown);
+    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, split || hc.grown, xv);
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
         grow(it);
         const bool compacted = forward(it, &rows);                   // alpha_mcts.rs:186
         S.slot_row = compacted ? B.slot_row.p : nullptr;
         join();
-        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, split || hc.grown);
+        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, split || hc.grown, xv);
     }
     launch_reduce_counters(st, S, G);
     HIPCHK(hipGetLastError());

@@ -200,7 +200,7 @@ def get_actions_for_player(player, states, ids, rnd, mcts_config, temp, seed, ru
         if len(ri):
             powed[ri, ci] = rules.powf(probs[ri, ci].astype(np.float32), inv_t)  # .pow_(1.0 / temp), :283 (one batched call)
         for i in range(n):
-            if nch[i] == 0:                    # :292 root.children.is_empty() -> EMPTY_MOVE
+            if nch[i] == 0 or float(powed[i].sum()) == 0.0:   # :292 all-zero row (e.g. iterations = 0) or root.children.is_empty() -> EMPTY_MOVE
                 continue
             codes[i] = weighted_select(powed[i], float(uni[i]))
         return rules.decode(states, codes)     # :301
@@ -314,6 +314,8 @@ def play_tictactoe(player1, player2, mcts_config, temp, seed=0xD1EE0001, num_gam
                     nz = row > 0
                     powed = np.zeros(TTT_ACTIONS, dtype=np.float32)
                     powed[nz] = np.power(row[nz].astype(np.float64), float(inv_t)).astype(np.float32)   # .pow_(1.0 / temp), :283
+                    if float(powed.sum()) == 0.0:
+                        continue                                                      # `prob_tensor.sum() == 0` -> EMPTY_MOVE too, versus.rs:286-293
                     acts[int(g)] = weighted_select(powed, float(uni[k]))
             elif pl.player_type == Agent.RANDOM:
                 for k, g in enumerate(ids):
