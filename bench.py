@@ -101,7 +101,7 @@ def _omp_search(job):
     return out
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=4, games_budget_s=90.0):
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=150.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
     `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
@@ -208,7 +208,7 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
     return out
 
 
-def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=420, games=4):
+def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=480, games=2):
     """cpu_baseline in a child process (its own thread-pool settings; killed by PID after timeout_s): the baseline is a
     report and must never hang the bench line"""
     import subprocess
@@ -284,7 +284,7 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--iterations", type=int, default=None, help="MCTS iterations (overrides the preset)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-games", type=int, default=4, help="whole games the CPU baseline also plays to completion (0 = extrapolation only)")
+    ap.add_argument("--cpu-games", type=int, default=2, help="whole games the CPU baseline also plays to completion (0 = extrapolation only)")
     ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--exp-per-game", type=float, default=0.0, help=argparse.SUPPRESS)

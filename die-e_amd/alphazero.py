@@ -166,7 +166,7 @@ def make_resnet(spec=BACKGAMMON):
 # --------------------------------------------------------------------------- AlphaZero (alphazero.rs:61-67)
 class AlphaZero:
     def __init__(self, engine, config, mcts_config, op, blob=None, train_device=None, seed=0xD1EE0001,
-                 rank=0, world=1, root=".", quiet=False, game=BACKGAMMON):
+                 rank=0, world=1, root=".", quiet=False, game=BACKGAMMON, train_backend=None):
         import torch
         self.engine, self.config, self.mcts_config, self.op = engine, config, mcts_config, op
         self.game = game                                            # handle_command::<T>, main.rs:119: the same driver for either game
@@ -191,8 +191,16 @@ class AlphaZero:
                 # passes (every workgroup resident at once, meeting on a device counter) would share the CUs with them
                 self._set_bn_coop(False)
         on_gpu = torch.device(self.device).type == "cuda"
-        # DIEE_TRAIN=torch: the all-PyTorch fp32 step (MIOpen convolutions); default on a GPU: the tower on the engine's kernels
-        self.model.engine_tower = on_gpu and game is BACKGAMMON and os.environ.get("DIEE_TRAIN", "engine") != "torch"
+        # The reference trains in fp32 (tch autograd, alphazero.rs:202-261), and so does the DEFAULT here: the all-PyTorch fp32 step
+        # ("fp32"; "torch" is the old name).  train_backend / DIEE_TRAIN = "bf16" (old name "engine") opts into the 3 x faster step
+        # whose tower runs on the engine's bf16 MFMA kernels (die-e_amd/train_ops.py; fp32 master weights and accumulation, bf16
+        # activations): its gradients sit within mixed-precision noise of fp32 (tests/test_train_gpu.py: 300-step loss curves,
+        # held-out policy KL / value MSE and an arena between the two resulting networks), not within fp32 rounding.
+        backend = (train_backend or os.environ.get("DIEE_TRAIN", "fp32")).lower()
+        if backend not in ("fp32", "torch", "bf16", "engine"):
+            raise ValueError(f"train backend {backend!r}: fp32 (default) or bf16")
+        self.train_backend = "bf16" if backend in ("bf16", "engine") and on_gpu and game is BACKGAMMON else "fp32"
+        self.model.engine_tower = self.train_backend == "bf16"
         # the whole step (forward, backward, Adam) replayed as one HIP graph for full batches (single-rank training only)
         self.use_graph = on_gpu and world == 1 and os.environ.get("DIEE_TRAIN_GRAPH", "1") != "0"
         self._graph = None

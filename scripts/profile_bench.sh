@@ -12,16 +12,16 @@ cd /tmp && export TMPDIR=/tmp
 W=/tmp/prof_$TAG; rm -rf "$W"; mkdir -p "$W"
 rocprofv3 --kernel-trace --stats -d "$W/full" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/${TAG}_line.json" 2> "$OUT/${TAG}_err.log"
 cp "$(find "$W/full" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
-# Pass 1b: the timed leg alone (one batch at a time): k_tower16<4,8,3>'s AverageNs here is what roofline.avg_launch_us must agree with
-rocprofv3 --kernel-trace --stats -d "$W/headline" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --pipeline 0 > "$OUT/${TAG}_headline_line.json" 2>> "$OUT/${TAG}_err.log"
+# Pass 1b: the timed leg alone (one batch at a time, records delivered; no HBM-only repeat): k_tower16<4,8,3>'s AverageNs here is what roofline.avg_launch_us must agree with
+rocprofv3 --kernel-trace --stats -d "$W/headline" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --pipeline 0 --hbm-only-steps 0 > "$OUT/${TAG}_headline_line.json" 2>> "$OUT/${TAG}_err.log"
 cp "$(find "$W/headline" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_headline_kernel_stats.csv"
 for G in 1024 32; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C -d "$W/pmc_${C}_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --games $G > /dev/null 2>> "$OUT/${TAG}_err.log"
+    rocprofv3 --kernel-trace --pmc $C -d "$W/pmc_${C}_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --hbm-only-steps 0 --games $G > /dev/null 2>> "$OUT/${TAG}_err.log"
   done
   F=$(find "$W/pmc_FETCH_SIZE_$G" -name '*counter_collection.csv' | head -1)
   Wr=$(find "$W/pmc_WRITE_SIZE_$G" -name '*counter_collection.csv' | head -1)
   SUF=""; [ $G = 32 ] && SUF="_32boards"
-  python3 "$ROOT/scripts/pmc_traffic.py" "$F" "$Wr" $G "$OUT/${TAG}_pmc_traffic$SUF.json" "python3 bench.py --no-cpu-baseline --max-steps 1 --pipeline 0 --games $G" > "$OUT/${TAG}_pmc_summary$SUF.txt" 2>&1
+  python3 "$ROOT/scripts/pmc_traffic.py" "$F" "$Wr" $G "$OUT/${TAG}_pmc_traffic$SUF.json" "python3 bench.py --no-cpu-baseline --max-steps 1 --pipeline 0 --hbm-only-steps 0 --games $G" > "$OUT/${TAG}_pmc_summary$SUF.txt" 2>&1
 done
 ls -la "$OUT" | grep "$TAG"

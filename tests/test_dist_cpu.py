@@ -199,3 +199,51 @@ def test_bench_main_on_two_gloo_ranks(oracle):
             tot += len(o["outcome"])
         per_rank.append(tot)
     assert per_rank == d["fragments_per_rank"]
+
+
+def _bench_worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), DIEE_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    import contextlib
+    import io
+    import torch
+    torch.set_num_threads(1)
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--games", "2", "--iterations", "4", "--pipeline", "2",
+                    "--hbm-only-steps", "1", "--no-cpu-baseline"], engine_factory=_StubEngine)
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_main_on_eight_gloo_ranks(oracle):
+    """the driver's 8-GPU launch (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) rehearsed once before hardware:
+    bench.main() on EIGHT gloo ranks with the stand-in engine -- the 8-way barriers, MAX(time) / SUM(counters), the all_gather
+    of 8 fragment counts, rank 0's single line with `fragments_per_rank` of length 8, the HBM-only and pipelined legs"""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + os.getpid() % 1000
+    world = 8
+    procs = [ctx.Process(target=_bench_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(res[r].strip() == "" for r in range(1, world))      # only rank 0 prints
+    lines = [l for l in res[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["stats"]["games"] == 8 * 2
+    assert len(d["fragments_per_rank"]) == 8 and sum(d["fragments_per_rank"]) == d["stats"]["fragments"] and min(d["fragments_per_rank"]) > 0
+    assert d["pipelined"]["games"] == 8 * 2 * 2 and d["value_hbm_only"] > 0 and "output_delivery_ms" in d
+    assert d["config"]["parallelism"].startswith("dp8")
+    # shards = block partition of the global ids: rank r plays games [2r, 2r + 2)
+    cfg = oracle.MctsCfg(iterations=4, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    want = [len(oracle.self_play_parallel(1, 2, cfg, 1.25, 0xD1EE0001, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=1, first_game_id=2 * r)["outcome"])
+            for r in range(world)]
+    assert want == d["fragments_per_rank"]

@@ -65,6 +65,40 @@ def test_learn_iteration_smoke(oracle, tmp_path):
     eng.close()
 
 
+def test_learn_loop_at_config5_parameters_reduced_batch(tmp_path):
+    """BASELINE configs[4] at its stated parameter values -- learn_iterations=2, self_play_iterations=4, num_epochs=4,
+    training_batch_size=256, iterations=100, temperature 1.25, arena of 400 games -- with num_self_play_batches reduced from 1024
+    to 64 (a 1024-game run takes minutes: bench.py --learn-loop / scripts/learn_config5.py): both learn iterations run every
+    phase (4 pipelined self-play batches, cumulative sp-j dirs, 4 epochs of fp32 training, fold-back, arena vs best_model) and the
+    wall clock per phase is printed"""
+    import time
+    import diee_amd
+    eng = diee_amd.Engine(0)
+    conf = az.AlphaZeroConfig(temperature=1.25, learn_iterations=2, self_play_iterations=4, num_epochs=4,
+                              training_batch_size=256, num_self_play_batches=64)
+    a = az.AlphaZero(eng, conf, diee_amd.MctsConfig.default(100), az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0),
+                     root=str(tmp_path), quiet=True)
+    assert a.train_backend == "fp32"                                             # the reference's arithmetic is the default
+    t = time.time()
+    rep = a.learn_parallel(arena=True, arena_games=400)
+    total = time.time() - t
+    assert len(rep) == 2
+    for r in rep:
+        assert r["fragments"] > 4 * 64 * 40 and np.isfinite(r["loss_last"]) and r["loss_last"] < r["loss_first"]
+        print(f"[config5, 64 games per batch] learn iteration {r['learn_iteration']}: {r['fragments']} fragments, self-play {r['self_play_s']:.1f} s, "
+              f"train {r['train_s']:.1f} s, loss {r['loss_first']:.3f} -> {r['loss_last']:.3f}, arena: {r['arena']}")
+    print(f"[config5, 64 games per batch] whole loop {total:.1f} s")
+    assert rep[0]["arena"] == "saved-as-best"
+    assert rep[1]["arena"] in ("new model was better!", "current best model is still better!",
+                               "new model vs current best was inconclusive, keeping current best!")
+    run = next((tmp_path / "data" / "backgammon").iterdir())
+    for li in range(2):
+        sizes = [len(az.AlphaZero.load_training_data(str(run / f"lrn-{li}" / f"sp-{j}"))["outcome"]) for j in range(4)]
+        assert sizes == sorted(sizes) and sizes[0] > 0 and sizes[3] == rep[li]["fragments"]      # cumulative memory per sp dir (Q20)
+        assert (tmp_path / "models" / "backgammon" / f"model_{li}.npy").exists()
+    eng.close()
+
+
 def test_cli_end_to_end_in_a_child_process(tmp_path):
     """F4: `diee.py -c tiny.toml -g backgammon learn | train | play` driven like die-e's binary (main.rs:15-216), a fresh
     child process per command; the model handed to `learn` is a libtorch-style .ot archive (F3)"""

@@ -1,7 +1,15 @@
-"""GPU numerics of the training-step kernels (die-e_amd/train_ops.py): forward, input gradient and weight gradient of
-the tower convolution against PyTorch fp32 autograd of the same op, and one whole training step against the
-all-PyTorch fp32 step.  Stated tolerance: bf16 operands with fp32 accumulation -> relative L2 error <= 1e-2 per tensor
-for a single convolution, <= 5e-2 for the gradients of the whole 40-layer network (bf16 activations end to end)."""
+"""GPU numerics of the training-step kernels (die-e_amd/train_ops.py) against PyTorch fp32 autograd -- the arithmetic the
+reference trains in (tch, alphazero.rs:202-261) and this build's DEFAULT training backend.  The bf16 engine step is OPT-IN
+(train_backend="bf16" / DIEE_TRAIN=bf16), and these are the tolerances it is held to, each asserted below:
+  * one tower convolution (forward, input gradient, weight gradient), one fused BatchNorm pass: relative L2 <= 1e-2 per tensor;
+  * the parameter gradients of the whole 40-layer step at random init: NOT within fp32 rounding -- the gradients of this
+    network are ill-conditioned in any bf16 arithmetic (PyTorch's own bf16 autocast: median 0.26) -- so: median relative L2
+    <= 0.35 over the parameter tensors, minimum cosine >= 0.85, and no worse than 1.4 x autocast (which is why fp32 is the default);
+  * what training with it does to a network, against fp32 training on the same fragments in the same order for 300 steps:
+    per-step losses within 5 % on >= 95 % of the steps and 2 % on average; on held-out fragments the two trained networks differ
+    (policy KL, value MSE, loss) by no more than 1.25 x what two fp32 trainings differ by when only the shuffle changes (the
+    reference shuffles with an unseeded thread_rng, alphazero.rs:203-204: that spread is its own run-to-run noise); and an arena of
+    400 games between the two networks ends inside 50 % +- 7.5 % (3 sigma)."""
 import importlib
 
 import numpy as np
@@ -143,8 +151,9 @@ torch.save(outs[0], sys.argv[1])
 
 
 def test_training_step_on_engine_kernels_tracks_the_fp32_step(oracle):
-    """one AlphaZero.train step (soft-label CE + MSE, BatchNorm in train mode, alphazero.rs:202-261): losses equal within
-    bf16 noise, parameter gradients within 5 % relative L2 of the fp32 autograd step, and the step descends"""
+    """one AlphaZero.train step of the opt-in bf16 backend (soft-label CE + MSE, BatchNorm in train mode, alphazero.rs:202-261)
+    against the fp32 autograd step: loss within 2e-3, parameter gradients within the tolerance this file states (median
+    relative L2 <= 0.35, cosine >= 0.85, no worse than 1.4 x PyTorch's bf16 autocast), and the step descends"""
     import torch
     import torch.nn.functional as Fn
     import diee_amd
@@ -191,6 +200,99 @@ def test_training_step_on_engine_kernels_tracks_the_fp32_step(oracle):
     assert noise < 1e-3
     # BatchNorm ran in train mode on the token path too: running statistics moved
     assert float(net.blocks[3].bn1.running_mean.abs().sum()) > 0
+
+
+def test_default_training_backend_is_fp32_and_bf16_is_opt_in(monkeypatch):
+    import diee_amd
+    az = importlib.import_module("die-e_amd.alphazero")
+    mk = lambda **kw: az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, 1, 64, 6), diee_amd.MctsConfig.default(4), az.OptimizerParams(1e-4, 1e-3),
+                                   blob=diee_amd.random_weights(0), train_device="cuda", quiet=True, **kw)
+    monkeypatch.delenv("DIEE_TRAIN", raising=False)
+    a = mk()
+    assert a.train_backend == "fp32" and not a.model.engine_tower              # what the reference does (tch fp32 autograd)
+    assert mk(train_backend="bf16").model.engine_tower
+    monkeypatch.setenv("DIEE_TRAIN", "bf16")
+    assert mk().train_backend == "bf16"
+    monkeypatch.setenv("DIEE_TRAIN", "fp16")
+    with pytest.raises(ValueError):
+        mk()
+
+
+def test_bf16_engine_training_tracks_fp32_training_over_300_steps(tmp_path):
+    """F1 evidence for the opt-in bf16 step (docstring of this file).  Three trainings of the same random-init network on the same
+    >= 20 k self-play fragments, 300+ steps of 256:
+        A   fp32 (the default backend = the reference's arithmetic), shuffle seeds 1000, 1001, ...
+        A'  bf16 engine step, the SAME shuffles: batch for batch the same data as A
+        B   fp32 again with OTHER shuffles -- the yardstick: the reference shuffles with an unseeded thread_rng
+            (alphazero.rs:203-204), so two of ITS runs differ from each other by this much
+    compared: A' against A loss for loss; the resulting networks on held-out fragments (loss, policy KL, value MSE), A' - A
+    against the yardstick B - A; and an arena of 400 games between the A and A' networks"""
+    import torch
+    import torch.nn.functional as Fn
+    import diee_amd
+    az = importlib.import_module("die-e_amd.alphazero")
+    versus = importlib.import_module("die-e_amd.versus")
+    eng = diee_amd.Engine(0)
+    blob = diee_amd.random_weights(0)
+    eng.load_weights(blob)
+    sp_cfg = diee_amd.MctsConfig(iterations=16, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    mem = eng.self_play_parallel(256, sp_cfg, 1.25, seed=0xF1, ref_quirks=True)
+    held = eng.self_play_parallel(24, sp_cfg, 1.25, seed=0xF2, ref_quirks=True, first_game_id=4096)
+    n = len(mem["outcome"])
+    assert n >= 20000 and len(held["outcome"]) >= 1500, (n, len(held["outcome"]))
+    mem = {k: mem[k] for k in ("outcome", "ps", "state")}
+    steps_per_epoch = -(-n // 256)
+    epochs = -(-300 // steps_per_epoch)
+    res = {}
+    for name, backend, seed0 in (("A", "fp32", 1000), ("A'", "bf16", 1000), ("B", "fp32", 2000)):
+        a = az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, epochs, 256, 256), sp_cfg, az.OptimizerParams(1e-4, 1e-3), blob=blob,
+                         train_device="cuda", quiet=True, train_backend=backend)
+        losses = []
+        for ep in range(epochs):
+            losses += a.train(mem, rng=np.random.default_rng(seed0 + ep), resident=ep > 0)
+        a.sync_engine()
+        res[name] = (np.array(losses), a.blob.copy())
+    lf, lb = res["A"][0], res["A'"][0]
+    assert len(lf) == len(lb) >= 300
+    relerr = np.abs(lb - lf) / lf
+    print(f"[F1] {len(lf)} steps on {n} fragments: loss fp32 {lf[0]:.4f} -> {lf[-1]:.4f}, bf16 {lb[0]:.4f} -> {lb[-1]:.4f}; per-step |d|/fp32: "
+          f"mean {relerr.mean():.4f}, p95 {np.quantile(relerr, 0.95):.4f}, max {relerr.max():.4f}")
+    # the two resulting networks on held-out fragments (eval mode: the running statistics each training accumulated)
+    st = torch.from_numpy(held["state"]).reshape(-1, 6, 4, 6).cuda()
+    ps = torch.from_numpy(held["ps"]).cuda(); oc = torch.from_numpy(held["outcome"].astype(np.float32)).unsqueeze(1).cuda()
+    out = {}
+    with torch.no_grad():
+        for name in res:
+            net = az.make_resnet().load_blob(res[name][1]).cuda().eval()
+            lg, v = net(st)
+            out[name] = (torch.log_softmax(lg.float(), 1), v.float(), float(Fn.cross_entropy(lg.float(), ps) + Fn.mse_loss(v.float(), oc)))
+
+    def kl(p, q):
+        return float((out[p][0].exp() * (out[p][0] - out[q][0])).sum(1).mean())
+
+    def vmse(p, q):
+        return float(((out[p][1] - out[q][1]) ** 2).mean())
+    hA, hA1, hB = out["A"][2], out["A'"][2], out["B"][2]
+    kl_bf, kl_run, mse_bf, mse_run = kl("A", "A'"), kl("A", "B"), vmse("A", "A'"), vmse("A", "B")
+    print(f"[F1] held-out ({len(oc)} fragments): loss fp32 {hA:.4f} / bf16 {hA1:.4f} / fp32 other shuffle {hB:.4f}; KL(fp32 || bf16) {kl_bf:.5f} nat vs "
+          f"KL(fp32 || fp32 other shuffle) {kl_run:.5f}; value MSE between the nets {mse_bf:.5f} vs {mse_run:.5f}")
+    # arena: the fp32-trained network against the bf16-trained one, 400 games (sides split as play() does); sigma of a fair
+    # match = 2.5 %, the bound is 3 sigma
+    e2 = diee_amd.Engine(0)
+    eng.load_weights(res["A"][1]); e2.load_weights(res["A'"][1])
+    P = versus.Player
+    r = versus.play(P(versus.Agent.MODEL, eng), P(versus.Agent.MODEL, e2), diee_amd.MctsConfig(iterations=24, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25),
+                    1.25, seed=0xA2E7A, num_games=400)
+    decided = r.wins_p1 + r.wins_p2
+    wr = r.wins_p1 / max(decided, 1)
+    print(f"[F1] arena fp32-trained vs bf16-trained: {r.wins_p1} : {r.wins_p2} ({r.draws} undecided) -> {wr:.3f}")
+    eng.close(); e2.close()
+    assert lf[-20:].mean() < 0.8 * lf[:20].mean()                               # 300 steps do train it
+    assert (relerr <= 0.05).mean() >= 0.95 and relerr.mean() <= 0.02, (relerr.mean(), np.quantile(relerr, 0.95), relerr.max())
+    # what bf16 arithmetic does to the trained network stays inside what the reference's own unseeded shuffle does to it
+    assert kl_bf <= 1.25 * kl_run and mse_bf <= 1.25 * mse_run, (kl_bf, kl_run, mse_bf, mse_run)
+    assert abs(hA1 - hA) <= max(0.03 * hA, 1.5 * abs(hB - hA)), (hA, hA1, hB)
+    assert decided >= 380 and abs(wr - 0.5) <= 0.075, (r.wins_p1, r.wins_p2, r.draws)
 
 
 def test_alphazero_train_engine_backend_with_and_without_graph(oracle, monkeypatch):
