@@ -80,6 +80,10 @@
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
+#ifndef DIEE_TOWER_DUPW
+#define DIEE_TOWER_DUPW 0        // timing build (results unchanged): every wave of the fused tower also requests the weight fragments of wave ^ 4 and waits for them like
+                                 // for its own -- the weight traffic of a 2 row-group x 4 column-group split of the workgroup (with -DDIEE_TOWER_ABLATE=7: its LDS traffic too)
+#endif
 #ifndef DIEE_TOWER_ABLATE
 #define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights, 6 ... 9 = fused tower without its LDS reads / weight loads (tower_layer16)
 #endif
@@ -1122,6 +1126,13 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #pragma unroll
         for (int q = 0; q < NFR; ++q) acc[f][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     bf16x8 a[2][MF];
+#if DIEE_TOWER_DUPW
+    u32x4 bq2[PF][NFR];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) bq2[i][q] = u32x4{0u, 0u, 0u, 0u};
+#endif
 #if DIEE_TOWER_STAGGER
     // the two waves of a SIMD run the same program and leave the layer barrier together: a short delay for the upper
     // half puts one wave's load phase beside its partner's MFMA phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 9)
@@ -1151,6 +1162,12 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
                 const u32x4* src = sp < 72 ? wp + (size_t)sp * 64 : wp_next + (size_t)(sp - 72) * 64;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) bq[u % PF][q] = src[(size_t)q * 72 * 64];
+#if DIEE_TOWER_DUPW
+                // the partner wave's fragments, in a ring of their own: consumed (waited for) where this wave's own are, PF k-steps later
+                const ptrdiff_t partner = (ptrdiff_t)(((wave ^ 4) - wave) * NFR) * 72 * 64;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { asm volatile("" :: "v"(bq2[u % PF][q])); bq2[u % PF][q] = src[partner + (ptrdiff_t)q * 72 * 64]; }
+#endif
             }
 #if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);

@@ -1,5 +1,7 @@
 """What bounds the 4-board fused tower: timing builds (wrong results) without the loop's LDS reads / weight loads.
     for n in 6 7 8 9; do DIEE_OUT=libdiee_abl$n.so DIEE_EXTRA_FLAGS=-DDIEE_TOWER_ABLATE=$n python die-e_amd/build.py; done
+    DIEE_OUT=libdiee_dupw.so DIEE_EXTRA_FLAGS=-DDIEE_TOWER_DUPW=1 python die-e_amd/build.py
+    DIEE_OUT=libdiee_dupw7.so DIEE_EXTRA_FLAGS="-DDIEE_TOWER_DUPW=1 -DDIEE_TOWER_ABLATE=7" python die-e_amd/build.py
     python scripts/fused_resource_ablate.py
 Each build in a fresh process: forward latency (us) of <4,8,3> at 1024 boards and <4,8,6> at 768 / 520 boards."""
 import os, subprocess, sys
@@ -13,7 +15,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         out.append(f"G={G}: " + " ".join(f"{e.conv_bench(G, v, 60)[2]:6.1f}" for _ in range(3)))
     print("   ".join(out)); sys.exit(0)
 names = {"libdiee.so": "product build", "libdiee_abl7.so": "7: A fragments read on every second k-step only", "libdiee_abl6.so": "6: no A-fragment reads in the loop",
-         "libdiee_abl8.so": "8: no weight loads in the loop", "libdiee_abl9.so": "9: neither (MFMAs + epilogue + barrier only)"}
+         "libdiee_abl8.so": "8: no weight loads in the loop", "libdiee_abl9.so": "9: neither (MFMAs + epilogue + barrier only)",
+         # round 4: the traffic of a 2 row-group x 4 column-group split of the workgroup's waves, priced without building it: every wave
+         # also requests (and waits for) the weight fragments of wave ^ 4 (DIEE_TOWER_DUPW=1), with and without half the A-fragment LDS reads
+         "libdiee_dupw.so": "DUPW: weight fragments requested twice per CU", "libdiee_dupw7.so": "DUPW + 7: 2 x 4 split's traffic (half the A reads, twice the weight requests)"}
 for lib, what in names.items():
     path = os.path.join(root, "die-e_amd", lib)
     if not os.path.exists(path): continue
