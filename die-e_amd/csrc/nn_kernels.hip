@@ -85,7 +85,7 @@
                                  // for its own -- the weight traffic of a 2 row-group x 4 column-group split of the workgroup (with -DDIEE_TOWER_ABLATE=7: its LDS traffic too)
 #endif
 #ifndef DIEE_TOWER_ABLATE
-#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights, 6 ... 9 = fused tower without its LDS reads / weight loads (tower_layer16)
+#define DIEE_TOWER_ABLATE 0      // diagnostic builds only: 1 = no main loop, 2 = no epilogue, 3 = in-kernel clock stamps, 4 = cluster tower re-reads two layers' weights, 6 ... 9 = fused tower without its LDS reads / weight loads, 12 = with half its weight loads (tower_layer16)
 #endif
 
 namespace diee {
@@ -1157,7 +1157,8 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
             bf16x8 b[NFR];
 #pragma unroll
             for (int q = 0; q < NFR; ++q) b[q] = __builtin_bit_cast(bf16x8, bq[u % PF][q]);
-            if (!kNoW) {
+            if (!kNoW && !(DIEE_TOWER_ABLATE == 12 && (u & 1))) {      // 12: timing build, weight fragments requested on every second k-step only = the
+                                                                       // weight traffic per board of an 8-boards-per-workgroup geometry (wrong results)
                 const int sp = it * 18 + u + PF;               // k-step to prefetch (of the next layer past 72)
                 const u32x4* src = sp < 72 ? wp + (size_t)sp * 64 : wp_next + (size_t)(sp - 72) * 64;
 #pragma unroll

@@ -11,13 +11,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import diee_amd
     e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
     out = []
-    for G, v in ((1024, 108), (768, 106), (520, 106)):
+    for G, v in ((1024, 108), (768, 106), (520, 106), (2048, 108)):
         out.append(f"G={G}: " + " ".join(f"{e.conv_bench(G, v, 60)[2]:6.1f}" for _ in range(3)))
     print("   ".join(out)); sys.exit(0)
 names = {"libdiee.so": "product build", "libdiee_abl7.so": "7: A fragments read on every second k-step only", "libdiee_abl6.so": "6: no A-fragment reads in the loop",
          "libdiee_abl8.so": "8: no weight loads in the loop", "libdiee_abl9.so": "9: neither (MFMAs + epilogue + barrier only)",
          # round 4: the traffic of a 2 row-group x 4 column-group split of the workgroup's waves, priced without building it: every wave
          # also requests (and waits for) the weight fragments of wave ^ 4 (DIEE_TOWER_DUPW=1), with and without half the A-fragment LDS reads
+         "libdiee_abl12.so": "12: weight fragments requested on every second k-step only (8 boards per workgroup's weight traffic)",
          "libdiee_dupw.so": "DUPW: weight fragments requested twice per CU", "libdiee_dupw7.so": "DUPW + 7: 2 x 4 split's traffic (half the A reads, twice the weight requests)"}
 for lib, what in names.items():
     path = os.path.join(root, "die-e_amd", lib)
