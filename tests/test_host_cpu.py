@@ -237,3 +237,16 @@ def test_train_puts_the_model_back_when_a_loss_is_not_finite(oracle):
             if torch.is_tensor(v):
                 assert torch.equal(v, opt_before[id(p)][k]), k
     assert np.isfinite(a.train(good)).all()                                      # and training goes on from there
+
+
+def test_design_time_tables_are_the_generators_output():
+    """DESIGN.md section 4's time tables are scripts/design_tables.py's output for the profile they name (one rocprofv3 summary + the
+    line of the same run, both committed under profiles/): nothing in them is typed in by hand"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("design_tables", os.path.join(ROOT, "scripts", "design_tables.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    tag = gen.current_tag()
+    assert tag and os.path.exists(os.path.join(ROOT, "profiles", f"{tag}_headline_kernel_stats.csv"))
+    block = doc[doc.index(gen.BEGIN):doc.index(gen.END) + len(gen.END) + 1]
+    assert block == gen.generate(tag), "run `python scripts/design_tables.py <tag> --update`"
