@@ -589,7 +589,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
     const auto saved_cl = W.cluster_table;
-    if (variant >= 100 && variant <= 111) W.tower_table = {{0, variant - 100}};
+    if (variant >= 100 && variant <= 113) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
     if (variant == 201 || variant == 202 || variant == 204 || variant == 208) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();

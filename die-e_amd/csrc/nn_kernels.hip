@@ -2121,6 +2121,11 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
         case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        // (10 / 11 are the pair tower, nn_host.cpp.)  12 / 13: ONE wave per SIMD with four column fragments -- half the A-fragment LDS reads
+        // of the 8-wave geometries at the same weight traffic -- and 9 / 18 weight k-steps in flight (512 VGPRs per lane to spend): round 4's
+        // probe of what a deeper ring buys that geometry (scripts/four_wave_probe.py); development only
+        case 12: tower16_launch<4, 4, 9>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        case 13: tower16_launch<4, 4, 18>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
     }
 }

@@ -41,7 +41,7 @@ def test_chunked_staging_and_grown_host_arrays_deliver_the_same_records(eng, mon
     a = eng.self_play_parallel(40, cfg2, 1.25, seed=8)
     monkeypatch.setenv("DIEE_DELIVER_STAGE_ROWS", "5")
     b = eng.self_play_parallel(40, cfg2, 1.25, seed=8)
-    assert same(a, b) and (a["outcome"] == 0).all() and len(a["outcome"]) >= 40 * 9
+    assert same(a, b) and (a["outcome"] == 0).all() and 40 * 6 <= len(a["outcome"]) <= 40 * 9      # (a skipped turn leaves no record)
 
 
 def test_views_of_the_engine_owned_arrays_and_the_block_pool(eng):

@@ -205,3 +205,15 @@ def test_cli_learn_train_play_for_tictactoe(tmp_path, monkeypatch, capsys):
     assert cli.main(["-c", str(conf), "-g", "tic-tac-toe", "play", "-a", "model", "-m", str(tmp_path / "t.npy"), "--agent-two", "random",
                      "-o", str(tmp_path)]) == 0
     assert "Number of Games: 400" in capsys.readouterr().out
+
+
+def test_arena_skips_the_turn_on_an_all_zero_probability_row(eng):
+    """get_actions_for_player returns EMPTY_MOVE when the pow'ed row sums to zero, not only when the root has no children
+    (versus.rs:286-293): with iterations = 0 the root is expanded but no child is ever visited -- every row is 0 / 0 -- so the
+    Model player passes every turn (it used to pick cell 0 and trip the legality assert once cell 0 was taken) and the Random
+    player, moving alone, wins every game"""
+    import importlib
+    versus = importlib.import_module("die-e_amd.versus")
+    cfg = diee_amd.MctsConfig(iterations=0, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    r = versus.play_tictactoe(versus.Player(versus.Agent.MODEL, eng), versus.Player(versus.Agent.RANDOM), cfg, 1.25, seed=5, num_games=12)
+    assert (r.wins_p1, r.wins_p2, r.draws) == (0, 12, 0)
