@@ -546,7 +546,12 @@ def main(argv=None, engine_factory=None):
             "stats": {"games": games, "plies_per_game": tot["plies"] / max(games, 1), "move_steps": tot["move_steps"],
                       "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
-                      "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"]},
+                      "fragments": tot["fragments"], "illegal_decodes": tot["illegal_decodes"],
+                      # SURVEY 8(d) item 4 (configs[3]): the tree one search builds for one game -- nodes created (56 B each: SoA statistics,
+                      # links, the 32-byte state) against the arena the engine reserves per live game ((iterations + 1) * 128 + 64 nodes)
+                      "tree_nodes_per_search": tot["children"] / max(tot["plies"], 1) + 1,
+                      "tree_bytes_per_search": 56 * (tot["children"] / max(tot["plies"], 1) + 1),
+                      "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64)},
             "roofline": dominant, "roofline_other": other,
             "fragments_per_rank": frags_per_rank,    # all_gather of the per-rank record counts; the records stay on their rank
         }

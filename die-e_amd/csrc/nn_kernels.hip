@@ -80,6 +80,9 @@
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
+#ifndef DIEE_TOWER_UNROLL4
+#define DIEE_TOWER_UNROLL4 1
+#endif
 #ifndef DIEE_TOWER_DUPW
 #define DIEE_TOWER_DUPW 0        // timing build (results unchanged): every wave of the fused tower also requests the weight fragments of wave ^ 4 and waits for them like
                                  // for its own -- the weight traffic of a 2 row-group x 4 column-group split of the workgroup (with -DDIEE_TOWER_ABLATE=7: its LDS traffic too)
@@ -1143,6 +1146,11 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #pragma unroll
     for (int f = 0; f < MF; ++f)
         if (!border_skip(SP, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
+    // One wave per SIMD (NW == 4): the 96 accumulators live in AGPRs and the register allocator permutes them across the back edge of this
+    // loop -- 132 v_accvgpr_read / _write / _mov per 18 k-steps (~10 % of the loop's issue slots, in front of the first MFMA of every
+    // trip); unrolled in full there is no back edge to permute across (DIEE_TOWER_UNROLL4, round 4).  The 8-wave geometries keep the loop.
+    constexpr int kUnrollIt = (DIEE_TOWER_UNROLL4 && NW == 4) ? 4 : 1;
+#pragma unroll kUnrollIt
     for (int it = 0; it < (DIEE_TOWER_ABLATE == 1 ? 0 : 4); ++it) {
 #pragma unroll
         for (int u = 0; u < 18; ++u) {

@@ -4,8 +4,8 @@
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/c4; for IT in 100 1600; do
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d /tmp/c4/it$IT --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --iterations $IT > "$OUT/config4_line_it$IT.json" 2> "$OUT/config4_err_it$IT.log"
+rm -rf /tmp/c4; : > "$OUT/config4_l2_hit.txt"; for IT in 100 1600; do
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d /tmp/c4/it$IT --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --hbm-only-steps 0 --iterations $IT > "$OUT/config4_line_it$IT.json" 2> "$OUT/config4_err_it$IT.log"
 python3 - "$IT" "$(find /tmp/c4/it$IT -name '*counter_collection.csv' | head -1)" <<'PY' >> "$OUT/config4_l2_hit.txt"
 import csv, re, sys
 from collections import defaultdict
