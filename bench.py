@@ -491,14 +491,14 @@ def main(argv=None, engine_factory=None):
         # (k_tower16p: a board group over two workgroups, 129 ... 512 boards) while more than 128 games are alive and as ONE
         # cluster launch (k_tower_cl: 8-workgroup clusters per board group) at 128 games or fewer; the two `roofline_other` rows
         # go by band (> 256 / <= 256 boards) as in earlier rounds; the 38 per-layer launches (k_conv3x3_sk) remain as the fallback and the test reference
-        # The dominant KERNEL is k_tower16<4,8,3>: 929 ... 1024 live games, the whole batch in one launch.  Its sampled launches are
+        # The dominant KERNEL is k_tower16<4,4,3> (the instantiation with BAND = 0): 929 ... 1024 live games, the whole batch in one launch.  Its sampled launches are
         # timed one to one, so `avg_launch_us` is that kernel's AverageNs in a rocprofv3 --kernel-trace --stats summary of the timed leg
         # (`bench.py --no-cpu-baseline --pipeline 0 --hbm-only-steps 0`, profiles/).  `roofline_other` keeps
         # the average over every fused-tower evaluation (257 ... 1024 boards; a compacted evaluation is up to three launches).
-        r_full = roof("k_tower16<4,8,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16; 929 ... 1024 boards = one pass of the chip)",
+        r_full = roof("k_tower16<4,4,3> (38 fused 3x3 conv layers + init block + head convs in one launch, v_mfma_f32_16x16x32_bf16, one wave per SIMD x 4 column fragments; 929 ... 1024 boards = one pass of the chip)",
                       tot["full_seconds"], tot["full_launches"], tot["full_flops"], pmc_traffic("diee::k_tower16<4"),
                       pmc_mfma("diee::k_tower16<4", MFMA_BUSY_FILE), MFMA_BUSY_FILE)
-        r_fused = roof("k_tower16 / k_tower16p<4>, every geometry (<4,8,3>, <4,8,6>, pair tower <= 512 boards): all evaluations of batches > 256 boards, timed per evaluation (a compacted evaluation is up to three launches)",
+        r_fused = roof("k_tower16 / k_tower16p<4>, every geometry (<4,4,3> at 513 ... 1024 boards, pair tower <= 512 boards): all evaluations of batches > 256 boards, timed per evaluation (a compacted evaluation is up to three launches)",
                        tot["tower_seconds"], tot["tower_launches"], tot["tower_flops"], pmc_traffic("diee::k_tower16<4"))
         r_cluster = roof("k_tower_cl (38 tower layers + head convs + policy FC in one launch, 8-workgroup clusters exchanging activations through tagged device-coherent loads, latency-bound) at <= 128 boards and k_tower16p<2> (two-board pair tower) at 129 ... 256: all evaluations of batches <= 256 boards, the same population as in earlier rounds; FLOPs counted: the 38 tower layers)",
                          tot["cluster_seconds"], tot["cluster_launches"], tot["cluster_flops"],

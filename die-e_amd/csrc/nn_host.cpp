@@ -156,7 +156,7 @@ void Engine::load_weights(const float* blob, size_t n) {
         net->pair_tower = false;
         fprintf(stderr, "[diee] pair tower: device %d is not 8 XCDs x 32 CUs (a partition?); using the single-workgroup geometries\n", device);
     }
-    if (!net->pair_tower) net->tower_table = {{928, 8}, {416, 6}, {256, 3}};
+    if (!net->pair_tower) net->tower_table = {{928, 5}, {416, 14}, {256, 3}};
     if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
@@ -416,8 +416,8 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
                 kind == 1 ? "fused tower" : kind == 2 ? "cluster tower" : "per-layer kernels", tgeom, W.tower_table.size(), W.cluster_table.size());
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        // kind 3: the whole chunk in ONE k_tower16<4,8,3> launch (geometry 8): the dominant kernel, sampled one to one
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, (kind == 1 && tgeom == 8) ? 3 : kind, -1, G});
+        // kind 3: the whole chunk in ONE launch of the full-chip instantiation (geometry 5, k_tower16<4,4,3>): the dominant kernel, sampled one to one
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * G * 24.0 * 2304.0 * 256.0, kind == 0 ? 38 : 1, (kind == 1 && tower_geometry_is_full_chip(tgeom)) ? 3 : kind, -1, G});
     }
     if (!heads_done) launch_conv3x3(st, 256, 2, actX, W.wconv[39].p, W.bconv[39].p, nullptr, hp, hv, G, 64);
     return fc_done;
@@ -498,7 +498,7 @@ bool nn_cluster_used(Engine& e) {
 void nn_disable_cluster(Engine& e) {
     if (!e.net) return;
     e.net->cluster_table.clear();
-    e.net->pair_tower = false; e.net->tower_table = {{928, 8}, {416, 6}, {256, 3}};   // the pair tower hands over inside its launch too
+    e.net->pair_tower = false; e.net->tower_table = {{928, 5}, {416, 14}, {256, 3}};   // the pair tower hands over inside its launch too
     uint32_t f = 0;
     e.d2h(&f, e.flags_dev.p, 1);
     e.sync();
@@ -589,7 +589,7 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     const int se = W.sample_every; W.sample_every = 0;
     const auto saved_table = W.tower_table;
     const auto saved_cl = W.cluster_table;
-    if (variant >= 100 && variant <= 113) W.tower_table = {{0, variant - 100}};
+    if (variant >= 100 && variant <= 114) W.tower_table = {{0, variant - 100}};
     else if (variant != 0) W.tower_table.clear();
     if (variant == 201 || variant == 202 || variant == 204 || variant == 208) { W.cluster_table = {{1 << 30, variant - 200}}; nn_set_conv_variant(0); }   // cluster tower, 2 / 4 boards per group
     else if (variant != 0) W.cluster_table.clear();

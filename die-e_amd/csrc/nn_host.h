@@ -23,7 +23,11 @@ struct NetWeights {
     // 4 boards per workgroup above 416 boards (border-aware fragment order: 22 % of the MFMAs are padding and not issued;
     // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
-    std::vector<TowerRule> tower_table = {{928, 8}, {512, 6}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
+    // Round 4: ONE wave per SIMD with four column fragments (geometry 5 = k_tower16<4,4,3>; 14 = the same code instantiated again for
+    // the band below one pass of the chip) replaces the 8-wave geometries 8 / 6: half the A-fragment LDS reads at the same weight
+    // traffic; its k loop is unrolled in full -- with the loop the accumulators (in AGPRs) were permuted across the back edge, 132
+    // v_accvgpr moves per 18 k-steps, which is what "62-67 %" above measured: 603 vs 634 us at 1024 boards, 514 vs 531 at 768.
+    std::vector<TowerRule> tower_table = {{928, 5}, {512, 14}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
                                     // pair (257 ... 512 boards) / 2 boards per pair (129 ... 256: 277 ... 298 us against the cluster tower's 313 ... 318)
     DevBuf<uint16_t> pair_ex;       // its exchange buffers (zeroed once)
     bool pair_tower = true;         // DIEE_TOWER_PAIR=0: the 2-board geometry instead (rounds 1-2)

@@ -80,6 +80,9 @@
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
+#ifndef DIEE_PAIR_UNROLL
+#define DIEE_PAIR_UNROLL 0
+#endif
 #ifndef DIEE_TOWER_UNROLL4
 #define DIEE_TOWER_UNROLL4 1
 #endif
@@ -1255,7 +1258,9 @@ struct RowMap {
     int main_cap;               // boards the mode-1 launch of this evaluation can take (0: there is none)
 };
 
-template <int GT, int NW, int PF>
+// BAND: no effect on the code -- a second instantiation of the same geometry for another band of live games, so that each band is a
+// row of its own in a rocprofv3 kernel summary (bench.py's per-launch figure for the full-chip band must agree with ONE such row)
+template <int GT, int NW, int PF, int BAND = 0>
 __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict__ x_in, const u32x4* __restrict__ wt,
                                                     const float* __restrict__ bias, uint16_t* __restrict__ x_out, int M,
                                                     RowMap rm,
@@ -1535,6 +1540,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
                                            Issue&& issue_peer, IssueNext&& issue_next) {
     constexpr int ROWS = GT * 24, MF = ROWS / 16, NQ = 2;
     constexpr bool SP = GT == 4;                                  // border-aware fragment order (4 boards: see border_skip)
+    constexpr int kPairUnrollIt = DIEE_PAIR_UNROLL ? 4 : 1;       // (round 4 experiment: the k loop unrolled in full, as in the 4-wave k_tower16)
     f32x4 acc[MF][NQ];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
@@ -1546,6 +1552,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
 #pragma unroll
     for (int f = 0; f < MF; ++f)
         if (!border_skip(SP, 0, f)) a[0][f] = *(const bf16x8*)(tin + baddr(0, f));
+#pragma unroll kPairUnrollIt
     for (int it = 0; it < 4; ++it) {
         if (it == 2 && half == 0) {                               // member 0: the second half of K is the other member's
             fetch_peer();
@@ -2039,7 +2046,7 @@ static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, c
                        (const u32x4*)wt, bias, x_out, G * 24);
 }
 
-template <int GT, int NW, int PF>
+template <int GT, int NW, int PF, int BAND = 0>
 static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G,
                            const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
                            const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr,
@@ -2048,10 +2055,10 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_tower16<GT, NW, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)k_tower16<GT, NW, PF, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_tower16<GT, NW, PF>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
+    hipLaunchKernelGGL((k_tower16<GT, NW, PF, BAND>), dim3((G + GT - 1) / GT), dim3(64 * NW), lds, st, x_in,
                        (const u32x4*)wt, bias, x_out, G * 24, rm, g_tower_dbg, (const BgState*)states, (const u32x4*)winit16, binit,
                        (const u32x4*)whead16, bhead, hp, hv);
 }
@@ -2100,12 +2107,12 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
     const int tail = n_upper % kFullChip;
     const int main_cap = n_upper < kFullChip ? 0 : (tail > kFullRest ? n_upper : n_upper - tail);
     if (main_cap > 0)
-        tower16_launch<4, 8, 3>(st, nullptr, wt16, bias, nullptr, main_cap, states, winit16, binit, whead16, bhead, hp, hv,
+        tower16_launch<4, 4, 3>(st, nullptr, wt16, bias, nullptr, main_cap, states, winit16, binit, whead16, bhead, hp, hv,
                                 RowMap{row_slot, n_rows, 1, main_cap});
     // the remainder launches go out whatever n_upper is: n_rows may fall short of it by any amount
     const int rest_max = n_upper < kFullChip ? n_upper : kFullChip - 1;
     if (rest_max > kRemSplit)
-        tower16_launch<4, 8, 6>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
+        tower16_launch<4, 4, 3, 1>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
                                 RowMap{row_slot, n_rows, 2, main_cap});
     if (pair_ex)      // the remainder of at most kRemSplit boards: the pair tower
         tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
@@ -2114,8 +2121,8 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
         tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,
                                 binit, whead16, bhead, hp, hv, RowMap{row_slot, n_rows, 3, main_cap});
 }
-// geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9: 16x16x32 MFMA (wt16 = 16-column fragments):
-// 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 3, 7, 8)
+// geometry 0/1: 32x32x16 MFMA (wt = 32-column fragments); 2..9, 14: 16x16x32 MFMA (wt16 = 16-column fragments):
+// 3 = 2 boards x 8 waves, 4/5 = 3/4 boards x 4 waves, 7/8 = 3/4 boards x 8 waves (the dispatch table uses 5 and 14 = 5 again, since round 4)
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
                   uint16_t* x_out, int G, const void* states, const void* winit16, const float* binit,
                   const void* whead16, const float* bhead, uint16_t* hp, float* hv) {
@@ -2129,16 +2136,14 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
         case 7: tower16_launch<3, 8, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         case 8: tower16_launch<4, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         case 9: tower16_launch<3, 8, 3>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
-        // (10 / 11 are the pair tower, nn_host.cpp.)  12 / 13: ONE wave per SIMD with four column fragments -- half the A-fragment LDS reads
-        // of the 8-wave geometries at the same weight traffic -- and 9 / 18 weight k-steps in flight (512 VGPRs per lane to spend): round 4's
-        // probe of what a deeper ring buys that geometry (scripts/four_wave_probe.py); development only
-        case 12: tower16_launch<4, 4, 9>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
-        case 13: tower16_launch<4, 4, 18>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
+        // (10 / 11 are the pair tower, nn_host.cpp.)  14: geometry 5 again, instantiated for the band below one pass of the chip (BAND)
+        case 14: tower16_launch<4, 4, 3, 1>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
         default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
     }
 }
 // geometries 2..9 can run the init block themselves (states != nullptr); 0 / 1 (32x32x16) need it launched in front
 bool tower_geometry_has_init(int geometry) { return geometry >= 2; }
+bool tower_geometry_is_full_chip(int geometry) { return geometry == 5 || geometry == 8; }    // 4 boards per workgroup, the instantiation of the full-chip band
 
 void nn_setup_kernels() {}
 
