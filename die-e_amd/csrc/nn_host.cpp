@@ -156,7 +156,7 @@ void Engine::load_weights(const float* blob, size_t n) {
         net->pair_tower = false;
         fprintf(stderr, "[diee] pair tower: device %d is not 8 XCDs x 32 CUs (a partition?); using the single-workgroup geometries\n", device);
     }
-    if (!net->pair_tower) net->tower_table = {{928, 5}, {416, 14}, {256, 3}};
+    if (!net->pair_tower) net->tower_table = {{928, 5}, {640, 14}, {416, 6}, {256, 3}};
     if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
     if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
     if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
@@ -498,7 +498,7 @@ bool nn_cluster_used(Engine& e) {
 void nn_disable_cluster(Engine& e) {
     if (!e.net) return;
     e.net->cluster_table.clear();
-    e.net->pair_tower = false; e.net->tower_table = {{928, 5}, {416, 14}, {256, 3}};   // the pair tower hands over inside its launch too
+    e.net->pair_tower = false; e.net->tower_table = {{928, 5}, {640, 14}, {416, 6}, {256, 3}};   // the pair tower hands over inside its launch too
     uint32_t f = 0;
     e.d2h(&f, e.flags_dev.p, 1);
     e.sync();

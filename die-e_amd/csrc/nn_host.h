@@ -27,7 +27,8 @@ struct NetWeights {
     // the band below one pass of the chip) replaces the 8-wave geometries 8 / 6: half the A-fragment LDS reads at the same weight
     // traffic; its k loop is unrolled in full -- with the loop the accumulators (in AGPRs) were permuted across the back edge, 132
     // v_accvgpr moves per 18 k-steps, which is what "62-67 %" above measured: 603 vs 634 us at 1024 boards, 514 vs 531 at 768.
-    std::vector<TowerRule> tower_table = {{928, 5}, {512, 14}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
+    // Below ~640 boards (fewer than 160 of 256 CUs busy: no power limit to give back to) the 8-wave geometry 6 is still the faster one.
+    std::vector<TowerRule> tower_table = {{928, 5}, {640, 14}, {512, 6}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
                                     // pair (257 ... 512 boards) / 2 boards per pair (129 ... 256: 277 ... 298 us against the cluster tower's 313 ... 318)
     DevBuf<uint16_t> pair_ex;       // its exchange buffers (zeroed once)
     bool pair_tower = true;         // DIEE_TOWER_PAIR=0: the 2-board geometry instead (rounds 1-2)

@@ -81,7 +81,7 @@
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
 #ifndef DIEE_PAIR_UNROLL
-#define DIEE_PAIR_UNROLL 0
+#define DIEE_PAIR_UNROLL 1         // the pair tower's k loop unrolled in full (round 4: 320 ... 390 us against 333 ... 406 at 300 ... 512 boards, profiles/r04h_pair_unroll_ab.txt)
 #endif
 #ifndef DIEE_TOWER_UNROLL4
 #define DIEE_TOWER_UNROLL4 1
@@ -1251,6 +1251,7 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 // capped by what the host launched for mode 1.  All three are the same arithmetic per output element (the 16x16x32
 // fused family), so WHICH launch evaluates a row never shows in its result.
 constexpr int kFullChip = 1024, kRemSplit = DIEE_REM_SPLIT, kFullRest = 928;
+constexpr int kFourWaveMin = 640;      // boards above which the 4-wave fused geometry beats the 8-wave one (NetWeights::tower_table says the same)
 struct RowMap {
     const uint32_t* row_slot;   // null: rows are slots (no compaction)
     const uint32_t* n_rows;
@@ -2111,8 +2112,13 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
                                 RowMap{row_slot, n_rows, 1, main_cap});
     // the remainder launches go out whatever n_upper is: n_rows may fall short of it by any amount
     const int rest_max = n_upper < kFullChip ? n_upper : kFullChip - 1;
-    if (rest_max > kRemSplit)
+    // (one wave per SIMD wins where most CUs are busy -- 525 vs 540 us at 768 boards, 489 vs 472 at 520: profiles/r04h_four_wave_probe.txt --;
+    // the host picks by its upper bound of the rows, the same bits either way)
+    if (rest_max > kFourWaveMin)
         tower16_launch<4, 4, 3, 1>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
+                                RowMap{row_slot, n_rows, 2, main_cap});
+    else if (rest_max > kRemSplit)
+        tower16_launch<4, 8, 6>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv,
                                 RowMap{row_slot, n_rows, 2, main_cap});
     if (pair_ex)      // the remainder of at most kRemSplit boards: the pair tower
         tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16, binit, whead16, bhead, hp, hv,
