@@ -80,6 +80,15 @@
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
+#ifndef DIEE_PAIR_BIAS_EARLY
+#define DIEE_PAIR_BIAS_EARLY 1
+#endif
+#ifndef DIEE_TOWER_BIAS_EARLY
+#define DIEE_TOWER_BIAS_EARLY 1
+#endif
+#ifndef DIEE_TOWER_EPI_OVERLAP
+#define DIEE_TOWER_EPI_OVERLAP 0
+#endif
 #ifndef DIEE_PAIR_UNROLL
 #define DIEE_PAIR_UNROLL 1         // the pair tower's k loop unrolled in full (round 4: 320 ... 390 us against 333 ... 406 at 300 ... 512 boards, profiles/r04h_pair_unroll_ab.txt)
 #endif
@@ -1132,6 +1141,15 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #pragma unroll
         for (int q = 0; q < NFR; ++q) acc[f][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     bf16x8 a[2][MF];
+    // One wave per SIMD: the layer's bias is requested HERE, a whole k loop ahead of the epilogue that adds it -- requested there, its L2
+    // round trip (and an s_waitcnt vmcnt(0) that also drains the next layer's weight ring) sat exposed at the end of every layer, with no
+    // second wave on the SIMD to fill it.  16 registers; the 8-wave geometries (256 VGPRs, already spilling) keep the late load.
+    constexpr bool kBiasEarly = DIEE_TOWER_BIAS_EARLY && NW == 4;
+    float4 bvq[NFR];
+    if (kBiasEarly) {
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) bvq[q] = *(const float4*)(bias + (wave * NFR + q) * 16 + (lane >> 4) * 4);
+    }
 #if DIEE_TOWER_DUPW
     u32x4 bq2[PF][NFR];
 #pragma unroll
@@ -1194,6 +1212,10 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
 #if DIEE_TOWER_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
 #else
+            // (DIEE_TOWER_EPI_OVERLAP, one wave per SIMD only -- the loop is unrolled, `it` is a constant: the LAST k-step of a layer is left to the
+            // scheduler, without the pattern and the fence below, so that the epilogue's residual reads and VALU of the fragments that are
+            // finished may move up between the MFMAs of the fragments that are not: nothing else fills the SIMD while one wave converts 24 tiles)
+            if (!(DIEE_TOWER_EPI_OVERLAP && kUnrollIt == 4 && it == 3 && u == 17))
             // interleave this k-step's loads between its MFMAs instead of issuing them as a block in front
             {
                 constexpr int dummy = 0; (void)dummy;
@@ -1206,33 +1228,42 @@ __device__ __forceinline__ void tower_layer16(char* tin, char* tout, const u32x4
                     else if (!kNoW && i < n_lds + NFR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!(DIEE_TOWER_EPI_OVERLAP && kUnrollIt == 4 && it == 3 && u == 17)) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
     }
     // epilogue.  The operands are swapped (weights as the MFMA's A, activations as its B), so in the 16x16 C/D
     // layout (col = lane&15, row = (lane>>4)*4 + i) a lane holds FOUR CONSECUTIVE CHANNELS of one board position:
     // one 8-byte LDS write (and residual read) per tile instead of four 2-byte ones.
-#pragma unroll
-    for (int q = 0; q < (DIEE_TOWER_ABLATE == 2 ? 0 : NFR); ++q) {
+    auto epilogue_tile = [&](int f, int q, const float4 bv) {
         const int n0 = (wave * NFR + q) * 16 + (lane >> 4) * 4;
-        const float4 bv = *(const float4*)(bias + n0);
+        const int r = tower_row<SP>(f, lane & 15);
+        if (ROWS % 16 != 0 && r >= ROWS) return;
+        const int off = r * 528 + n0 * 2;
+        float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
+        if (RES) {                                            // y = relu(conv2(h) + x), in place over x
+            const uint2 rv = *(const uint2*)(tout + off);
+            v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
+            v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
+        }
+        v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
+        uint2 o;
+        o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+        o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+        *(uint2*)(tout + off) = o;
+    };
+    if (kBiasEarly) {
+        // fragment-major, the order the last k-step finishes the tiles in (see above)
 #pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int r = tower_row<SP>(f, lane & 15);
-            if (ROWS % 16 != 0 && r >= ROWS) continue;
-            const int off = r * 528 + n0 * 2;
-            float v0 = acc[f][q][0] + bv.x, v1 = acc[f][q][1] + bv.y, v2 = acc[f][q][2] + bv.z, v3 = acc[f][q][3] + bv.w;
-            if (RES) {                                            // y = relu(conv2(h) + x), in place over x
-                const uint2 rv = *(const uint2*)(tout + off);
-                v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
-                v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
-            }
-            v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; v2 = v2 > 0.0f ? v2 : 0.0f; v3 = v3 > 0.0f ? v3 : 0.0f;
-            uint2 o;
-            o.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-            o.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-            *(uint2*)(tout + off) = o;
+        for (int f = 0; f < (DIEE_TOWER_ABLATE == 2 ? 0 : MF); ++f)
+#pragma unroll
+            for (int q = 0; q < NFR; ++q) epilogue_tile(f, q, bvq[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < (DIEE_TOWER_ABLATE == 2 ? 0 : NFR); ++q) {
+            const float4 bv = *(const float4*)(bias + (wave * NFR + q) * 16 + (lane >> 4) * 4);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) epilogue_tile(f, q, bv);
         }
     }
 #if DIEE_TOWER_ABLATE != 5      // 5: timing experiment, what the one barrier per layer costs (wrong results)
@@ -1542,6 +1573,11 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
     constexpr int ROWS = GT * 24, MF = ROWS / 16, NQ = 2;
     constexpr bool SP = GT == 4;                                  // border-aware fragment order (4 boards: see border_skip)
     constexpr int kPairUnrollIt = DIEE_PAIR_UNROLL ? 4 : 1;       // (round 4 experiment: the k loop unrolled in full, as in the 4-wave k_tower16)
+    float4 bvq[NQ];                                               // the layer's bias, requested a k loop ahead of the epilogue (one wave per SIMD: see tower_layer16)
+    if (DIEE_PAIR_BIAS_EARLY) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bvq[q] = *(const float4*)(bias + half * 128 + (wave * NQ + q) * 16 + (lane >> 4) * 4);
+    }
     f32x4 acc[MF][NQ];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
@@ -1606,7 +1642,7 @@ __device__ __forceinline__ void pair_layer(char* tin, char* tout, const u32x4* w
     for (int q = 0; q < NQ; ++q) {
         const int nl = (wave * NQ + q) * 16 + (lane >> 4) * 4;    // channel inside this member's half
         const int n0 = half * 128 + nl;
-        const float4 bv = *(const float4*)(bias + n0);
+        const float4 bv = DIEE_PAIR_BIAS_EARLY ? bvq[q] : *(const float4*)(bias + n0);
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int r = tower_row<SP>(f, lane & 15);
