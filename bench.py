@@ -101,7 +101,7 @@ def _omp_search(job):
     return out
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=150.0):
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=75.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
     `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
