@@ -563,7 +563,10 @@ def main(argv=None, engine_factory=None):
                     "into page-locked host arrays on a second stream while the next move-steps search; host_ms = enqueueing those + the wait for "
                     "the last copy after the last move-step"}
         if hbm is not None:
+            # value_hbm_only covers the FIRST hbm_only_steps batches only (batches differ by +-2 % in length): compare it with
+            # value_delivered_same_seeds, the delivered rate of those very batches -- not with `value`, which covers all K
             out["value_hbm_only"] = hbm["games"] / hbm["seconds"]
+            out["value_delivered_same_seeds"] = hbm["games"] / sum(step_s[:hbm["steps"]])      # (N > 1: on rank 0's clock)
             out["output_delivery_ms"] = sum(hbm["same_seed_delta_ms"]) / len(hbm["same_seed_delta_ms"])
             out["output_delivery"].update(hbm_only_steps=hbm["steps"], same_seed_delta_ms=hbm["same_seed_delta_ms"],
                                           delivered_over_hbm_only=(hbm["seconds"] / hbm["steps"]) / (sum(step_s[:hbm["steps"]]) / hbm["steps"]))
