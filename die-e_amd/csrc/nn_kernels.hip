@@ -80,6 +80,9 @@
 #ifndef DIEE_CL_ABLATE
 #define DIEE_CL_ABLATE 0          // timing experiments on the cluster tower: 1 = no MFMA loop, 2 = no partial-tile exchange, 3 = no weight loads
 #endif
+#ifndef DIEE_CL_SPLIT4_SMALL
+#define DIEE_CL_SPLIT4_SMALL 0
+#endif
 #ifndef DIEE_PAIR_BIAS_EARLY
 #define DIEE_PAIR_BIAS_EARLY 1
 #endif
@@ -2060,8 +2063,13 @@ bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint
     const ClusterHeads hd{(const u32x4*)whead, bhead, (const u32x4*)wfc, bfc, hv, logits};
     if (grown) *grown = false;
     switch (boards_per_group) {
+#if DIEE_CL_SPLIT4_SMALL      // timing experiment (another summation order than the per-layer reference): K split over 4 waves, one per SIMD, at 1 / 2 boards per cluster
+        case 1: return tower_cl_launch<1, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 2: return tower_cl_launch<2, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+#else
         case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
         case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+#endif
         case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
         case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);     // K split over 4 waves (one per SIMD)
         default: return false;

@@ -123,7 +123,7 @@ def test_border_aware_fragments_are_bit_identical(oracle, monkeypatch):
     states = oracle.random_walk_states(33, 12)[:1001]           # ragged: last workgroup has one board
     assert len(states) == 1001
     out = []
-    for geom in (8, 6, 5, 9):                                   # 4 boards (8 waves PF 3 / 6, 4 waves) vs 3 boards dense
+    for geom in (8, 6, 5, 14, 9):                               # 4 boards (8 waves PF 3 / 6; round 4's product: 4 waves, k loop unrolled, both instantiations) vs 3 boards dense
         monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
         e = diee_amd.Engine(0); e.load_weights(blob)
         out.append(e.forward_t(states)); out.append(e.forward_t(states[:7]))
