@@ -42,11 +42,12 @@ def conv_bn(x, conv, bn):
 
 
 @torch.no_grad()
-def forward_t(net, planes, dtype=torch.float32, shape=(6, 4, 6)):
+def forward_t(net, planes, dtype=torch.float32, shape=(6, 4, 6), device=None):
     """planes [n,144] (c*24+p) -> (softmax policy [n,1352], tanh value [n]); nnet.rs:120-133, train=false
-    (shape = the game's input planes: (6, 4, 6) backgammon, (3, 3, 3) tic-tac-toe)"""
-    x = torch.as_tensor(planes, dtype=torch.float32).reshape(-1, *shape).to(dtype)
-    cast = lambda t: tuple(cast(u) for u in t) if isinstance(t, tuple) else t.to(dtype)
+    (shape = the game's input planes: (6, 4, 6) backgammon, (3, 3, 3) tic-tac-toe; device: where PyTorch evaluates it --
+    the GPU tests run the fp32 restatement at full batch sizes on "cuda", still fp32 and still not the engine's kernels)"""
+    x = torch.as_tensor(planes, dtype=torch.float32).reshape(-1, *shape).to(device=device, dtype=dtype)
+    cast = lambda t: tuple(cast(u) for u in t) if isinstance(t, tuple) else t.to(device=device, dtype=dtype)
     net = {k: cast(v) if k != "blocks" else [cast(b) for b in v] for k, v in net.items()}
     x = torch.relu(conv_bn(x, *net["init"]))
     for c1, b1, c2, b2 in net["blocks"]:                       # ResBlock::forward_t, nnet.rs:24-34
@@ -56,4 +57,4 @@ def forward_t(net, planes, dtype=torch.float32, shape=(6, 4, 6)):
     logits = torch.relu(conv_bn(x, pc, pbn)).flatten(1) @ pw.T + pb
     vc, vbn, vw, vb = net["v"]
     value = torch.tanh(torch.relu(conv_bn(x, vc, vbn)).flatten(1) @ vw.T + vb)
-    return torch.softmax(logits, 1).float().numpy(), value[:, 0].float().numpy(), logits.float().numpy()
+    return torch.softmax(logits, 1).float().cpu().numpy(), value[:, 0].float().cpu().numpy(), logits.float().cpu().numpy()

@@ -3,6 +3,7 @@ weights.  Stated tolerance (bf16 storage of weights and activations, fp32 accumu
 max |policy - ref| <= 2e-3 absolute, |value - ref| <= 1e-2."""
 import numpy as np
 import pytest
+import torch            # (before the engine is created: PyTorch's bundled HIP runtime has to initialise first where both are used)
 
 pytestmark = pytest.mark.gpu
 
@@ -351,6 +352,40 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     assert same_support == 1.0                  # legal plays are integer work: identical
     # measured (round 2): agreement 0.992, TV mean 0.0010, p95 0.0100, max 0.0183; bounds = 3 x measured
     assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.06
+
+
+def test_search_with_bf16_net_tracks_search_with_fp32_net_at_1024_roots(setup, oracle):
+    """the same comparison at BASELINE configs[1]'s own size -- 1024 roots x iterations = 100, roots from the opening to the bear-off --:
+    the oracle's search is driven by the fp32 restatement evaluated by PyTorch at the full batch of 1024 (on the GPU, in fp32: 101
+    evaluations of 1.1 TFLOP would take minutes on the host), the engine's by its bf16 network through the dispatch the headline
+    workload takes (k_tower16<4,4,3> at 1024 boards, compaction and all)"""
+    import diee_amd
+    from oracle.nn_ref import forward_t
+    e, net, _ = setup
+    n, iters = 1024, 100
+    walk = oracle.random_walk_states(4242, 60)
+    states = walk[np.linspace(3, len(walk) - 1, n).astype(int)]
+    to_dev = lambda t: tuple(to_dev(u) for u in t) if isinstance(t, tuple) else t.to("cuda")
+    dev_net = {k: to_dev(v) if k != "blocks" else [to_dev(b) for b in v] for k, v in net.items()}      # the weights move once
+
+    def fn(states_u8):
+        st = states_u8.view(oracle.BG_STATE).reshape(-1)
+        p, v, _ = forward_t(dev_net, oracle.planes_batch(st), device="cuda")
+        return p, v
+    ocfg = oracle.MctsCfg(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    gcfg = diee_amd.MctsConfig(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
+    _, probs, _, _ = oracle.alpha_mcts_parallel(1, states, ocfg, oracle.make_eval(fn, 1352), None, 0xD1EE0001, 0, gids, rds, 1)
+    r = e.alpha_mcts_parallel(states, gcfg, 0xD1EE0001, 0, gids, rds, ref_quirks=True)
+    ok = ~np.isnan(probs).any(1)
+    a, b = np.nan_to_num(probs[ok]), np.nan_to_num(r["probs"][ok])
+    tv = 0.5 * np.abs(a - b).sum(1)
+    agree = (a.argmax(1) == b.argmax(1)).mean()
+    same_support = ((a > 0) == (b > 0)).all(1).mean()
+    print(f"[nn-parity] search fp32 vs bf16 at BASELINE size, {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.4f}, "
+          f"TV mean {tv.mean():.4f} / p95 {np.quantile(tv, 0.95):.4f} / max {tv.max():.4f}, identical support {same_support:.3f}")
+    assert ok.sum() >= 1000 and same_support == 1.0
+    assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.1
 
 
 def test_pair_tower_is_bit_identical_to_the_fused_geometries(oracle, monkeypatch):
