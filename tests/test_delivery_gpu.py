@@ -75,3 +75,20 @@ def test_pipelined_batches_deliver_per_batch_what_single_calls_deliver(eng):
             assert m["game"].min() >= first and m["game"].max() < first + n
     finally:
         eng.set_invariant_nn(False)
+
+
+def test_growth_at_batch_scale(eng, monkeypatch):
+    """512 games played to completion (~55 k records, 330 MB): the host arrays sized for 16 records per game grow several times while
+    copies are in flight, the staging buffer of 1 000 rows takes tens of rounds per busy move-step -- the same bytes as the default"""
+    cfg = diee_amd.MctsConfig(iterations=3, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    ref = eng.self_play_parallel(512, cfg, 1.25, seed=77, copy=False)
+    assert len(ref["outcome"]) == ref["stats"]["fragments"] > 512 * 60
+    monkeypatch.setenv("DIEE_DELIVER_ROWS_PER_GAME", "16")
+    monkeypatch.setenv("DIEE_DELIVER_STAGE_ROWS", "1000")
+    out = eng.self_play_parallel(512, cfg, 1.25, seed=77, copy=False)
+    assert same(out, ref)
+    # order of the records: by the move-step that removed the game, then by game (a game's records are contiguous and in play order)
+    g = ref["game"]
+    starts = np.flatnonzero(np.r_[True, g[1:] != g[:-1]])
+    assert len(starts) == len(np.unique(g)) == 512                          # every game exactly one contiguous run
+    out["free"](); ref["free"]()
