@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r04j_mfma_busy.json", "r04j_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 4: the 4-wave fused tower)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r04i_pmc_traffic.json", "r04i_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r04w_mfma_busy.json", "r04w_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 4: the 4-wave fused tower)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = "r04w_pmc_traffic.json", "r04w_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
 
 
 def host_cores():
