@@ -793,11 +793,11 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
         for (int d = 0; d < PD; ++d)
 #pragma unroll
             for (int f = 0; f < MF; ++f) a[d][f] = *(const bf16x8*)(smem + base[d % 9][f] + (d / 9) * 32);
+        // next layer's fragments (the head convs' after layer 37 where this workgroup runs them; last layer: reloads its own, unused)
+        const u32x4* whp = heads ? hd.whead + ((size_t)(nslice < 2 ? nslice : 0) * 144 + wave * KS) * 64 + lane : wp;
 #if DIEE_TOWER_ABLATE == 4
         const u32x4* wn = wp + (size_t)(l & 1) * kTowerLayerStride;                  // timing experiment: weights stay L2-resident (wrong results)
 #else
-        // next layer's fragments (the head convs' after layer 37 where this workgroup runs them; last layer: reloads its own, unused)
-        const u32x4* whp = heads ? hd.whead + ((size_t)(nslice < 2 ? nslice : 0) * 144 + wave * KS) * 64 + lane : wp;
         const u32x4* wn = l < 37 ? wp + (size_t)(l + 1) * kTowerLayerStride : (heads && nslice < 2) ? whp : wp + (size_t)37 * kTowerLayerStride;
 #endif
         const u32x4* wc = l < 38 ? wp + (size_t)l * kTowerLayerStride : whp;         // this layer's
