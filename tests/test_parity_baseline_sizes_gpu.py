@@ -9,7 +9,7 @@ run the geometry the metric is quoted on:
   * the same at 900 roots, where the engine COMPACTS the evaluation (k_row_map: rows of slots whose leaf was terminal
     are not evaluated above 256 live games; 929 ... 1024 run plain) -- compaction held to the oracle, not to itself;
   * diee_self_play vs oracle.self_play_parallel (alpha_parallel.rs:101-231): 1024 games played TO COMPLETION, the one
-    run that crosses every network dispatch band (k_tower16<4,8,3> -> <4,8,6> -> pair tower k_tower16p<4> -> <2> ->
+    run that crosses every network dispatch band (k_tower16<4,4,3> -> its second instantiation -> <4,8,6> -> pair tower k_tower16p<4> -> <2> ->
     k_tower_cl<4,8> ... <1,8>, with and without the growth workgroups in the cluster launch) with the compaction
     switching off at 256 live games; ps / state / outcome / game / order and every counter equal;
   * 1024 roots x iterations = 1600 (configs[3]: the deep tree, 205 k-node arenas) once, quirks on.
@@ -17,6 +17,8 @@ run the geometry the metric is quoted on:
 The oracle's evaluator is the engine's own ResNet called back through diee_nn_forward on the same batch the reference
 would push (all N slots), so both sides see identical priors and values; everything else is the oracle's C restatement
 of the reference's loops.  The C oracle needs 1.6 s (1024 x 100) / 6 s (1024 x 400) / ~15 s (self-play) on one core."""
+import os
+
 import numpy as np
 import pytest
 
@@ -164,3 +166,24 @@ def test_self_play_config2_whole_workload_bit_exact(eng, oracle):
         assert out["stats"][key] == ref["stats"][key], key
     assert out["stats"]["plies"] == int(ref["plies"].sum())
     assert out["stats"]["illegal_decodes"] == 0 == ref["stats"]["illegal_decodes"]
+
+
+@pytest.mark.skipif(os.environ.get("DIEE_LONG_TESTS") != "1", reason="~4 minutes (3 of them the single-core C oracle): DIEE_LONG_TESTS=1")
+def test_self_play_config3_per_gpu_whole_workload_bit_exact(eng, oracle):
+    """BASELINE configs[2] as ONE GPU sees it -- 1024 games x iterations = 400 played to completion (~37 M expansions, ~147 k
+    evaluations, ~110 k records) -- against the oracle, record for record and bit for bit.  Opt-in for its length; the run of
+    round 4's final build is kept in profiles/."""
+    n, iters = 1024, 400
+    ocfg, gcfg = cfgs(oracle, iters)
+    ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED + 31, gpu_eval(eng, oracle), None, ref_quirks=1, first_game_id=0)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 31, ref_quirks=True, first_game_id=0)
+    assert out["stats"]["move_steps"] == ref["steps"] > 250
+    assert len(out["outcome"]) == len(ref["outcome"]) > 90 * n
+    assert (out["game"] == ref["game"]).all() and (out["outcome"] == ref["outcome"]).all()
+    assert (out["state"].view(np.uint32) == ref["state"].view(np.uint32)).all()
+    assert (out["ps"].view(np.uint32) == ref["ps"].view(np.uint32)).all()
+    for key in COUNTERS[:-1]:
+        assert out["stats"][key] == ref["stats"][key], key
+    assert out["stats"]["plies"] == int(ref["plies"].sum())
+    print(f"[parity] configs[2] per GPU, whole workload: {len(out['outcome'])} records, {out['stats']['expansions']} expansions, "
+          f"{out['stats']['nn_evals']} evaluations, {out['stats']['move_steps']} move-steps: bit-exact")
