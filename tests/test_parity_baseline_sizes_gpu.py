@@ -187,3 +187,23 @@ def test_self_play_config3_per_gpu_whole_workload_bit_exact(eng, oracle):
     assert out["stats"]["plies"] == int(ref["plies"].sum())
     print(f"[parity] configs[2] per GPU, whole workload: {len(out['outcome'])} records, {out['stats']['expansions']} expansions, "
           f"{out['stats']['nn_evals']} evaluations, {out['stats']['move_steps']} move-steps: bit-exact")
+
+
+@pytest.mark.skipif(os.environ.get("DIEE_LONG_TESTS") != "2", reason="~30 minutes (the single-core C oracle and 590 k evaluator call-backs): DIEE_LONG_TESTS=2")
+def test_self_play_config4_deep_tree_whole_workload_bit_exact(eng, oracle):
+    """BASELINE configs[3] -- 1024 games x iterations = 1600, simulate_round_limit = 400 -- played to completion against the oracle,
+    record for record and bit for bit (the deep tree: 205 k-node arenas, ~16 k nodes per search).  Opt-in for its length."""
+    n, iters = 1024, 1600
+    ocfg, gcfg = cfgs(oracle, iters)
+    ref = oracle.self_play_parallel(1, n, ocfg, 1.25, SEED + 37, gpu_eval(eng, oracle), None, ref_quirks=1, first_game_id=0)
+    out = eng.self_play_parallel(n, gcfg, 1.25, SEED + 37, ref_quirks=True, first_game_id=0)
+    assert out["stats"]["move_steps"] == ref["steps"] > 250
+    assert len(out["outcome"]) == len(ref["outcome"]) > 90 * n
+    assert (out["game"] == ref["game"]).all() and (out["outcome"] == ref["outcome"]).all()
+    assert (out["state"].view(np.uint32) == ref["state"].view(np.uint32)).all()
+    assert (out["ps"].view(np.uint32) == ref["ps"].view(np.uint32)).all()
+    for key in COUNTERS[:-1]:
+        assert out["stats"][key] == ref["stats"][key], key
+    assert out["stats"]["plies"] == int(ref["plies"].sum())
+    print(f"[parity] configs[3], whole workload: {len(out['outcome'])} records, {out['stats']['expansions']} expansions, "
+          f"{out['stats']['nn_evals']} evaluations, {out['stats']['move_steps']} move-steps: bit-exact")
