@@ -4,6 +4,8 @@ engine's own ResNet (called back through diee_nn_forward), so priors and values 
 sides and every tree statistic, policy target and game record must agree BIT-EXACTLY."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -327,3 +329,21 @@ def test_one_wave_and_two_wave_tree_kernels_agree(oracle, monkeypatch, n, iters)
         for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
             assert a["stats"][key] == b["stats"][key], key
     assert a["stats"]["terminal_hits"] > 0
+
+
+@pytest.mark.skipif(os.environ.get("DIEE_LONG_TESTS") != "3", reason="~8 minutes (single-core C oracle in lockstep, 37 k merged evaluator call-backs of 4096 rows): DIEE_LONG_TESTS=3")
+def test_pipelined_leg_whole_workload_bit_exact_vs_lockstep_oracle(eng, oracle):
+    """bench.py's second figure at its full size -- FOUR self_play_parallel batches of 1024 games, iterations = 100, played side by side
+    to completion through diee_self_play_multi (the learn loop's self_play_iterations = 4) -- against the oracle's lockstep restatement:
+    every batch's records, policy targets, outcomes and counters identical.  Opt-in for its length."""
+    ocfg, gcfg = cfgs(oracle, 100)
+    batches = [(1024, 0, SEED + 0x9E37 * i) for i in range(4)]
+    ev, calls = gpu_eval(eng, oracle)
+    ref, total = oracle.self_play_multi(1, batches, ocfg, 1.25, ev, None, ref_quirks=1)
+    out = eng.self_play_multi(batches, gcfg, 1.25, ref_quirks=True)
+    assert max(o["stats"]["move_steps"] for o in out) == total
+    recs = 0
+    for (n, first, seed), m, r in zip(batches, out, ref):
+        _cmp_batch(m, r, n)
+        recs += len(m["outcome"])
+    print(f"[parity] pipelined leg, 4 x 1024 games x iterations 100 to completion: {recs} records, {total} move-steps: bit-exact per batch vs the lockstep oracle")
