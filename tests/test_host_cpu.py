@@ -250,3 +250,26 @@ def test_design_time_tables_are_the_generators_output():
     assert tag and os.path.exists(os.path.join(ROOT, "profiles", f"{tag}_headline_kernel_stats.csv"))
     block = doc[doc.index(gen.BEGIN):doc.index(gen.END) + len(gen.END) + 1]
     assert block == gen.generate(tag), "run `python scripts/design_tables.py <tag> --update`"
+
+
+@pytest.mark.parametrize("a1,a2,limit", [("Model", "Model", 400), ("Model", "Random", 400), ("Random", "Model", 30), ("Random", "Random", 400)])
+def test_arena_driver_equals_an_independent_restatement_of_versus_rs(oracle, a1, a2, limit):
+    """die-e_amd/versus.py::play (vectorised over the live games, behind a backend interface) against oracle/arena_ref.py, a second
+    restatement of versus.rs:160-318 written game by game in the reference's own control flow: wins, rounds, the winner of every game
+    and every final state equal -- the driver's logic (side partition, Player 1's games first, EMPTY_MOVE -> skip_turn without a winner
+    check, the round limit as a draw, the second half of the games starting with the other side) is held to something that is not itself"""
+    from oracle import arena_ref
+    from oracle.arena_backend import OracleRules, OracleSearch
+    cfg = diee_amd.MctsConfig.default(5)
+    ev = oracle.hash_eval_fn()
+    P = versus.Player
+    res = versus.play(P(a1), P(a2), cfg, 1.25, seed=77, num_games=12, round_limit=limit, rules=OracleRules(),
+                      search1=OracleSearch(ev, oracle.game(1)) if a1 == "Model" else None,
+                      search2=OracleSearch(ev, oracle.game(1)) if a2 == "Model" else None)
+    ref = arena_ref.play(a1, a2, ev, ev, cfg, 1.25, 77, 12, limit, ectx=oracle.game(1))
+    assert (res.wins_p1, res.wins_p2, res.draws, res.rounds) == (ref["wins_p1"], ref["wins_p2"], ref["draws"], ref["rounds"])
+    assert {g.initial_state["id"]: g.winner for g in res.games} == ref["winners"]
+    for g in range(12):
+        assert res.final_states[g].tobytes() == ref["final"][g].tobytes(), g
+    if limit < 400:
+        assert res.draws > 0                                         # the round limit ended games as draws (versus.rs:235)
