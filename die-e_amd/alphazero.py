@@ -540,9 +540,13 @@ class AlphaZero:
             t_sp = time.time() - t_sp
             mem = self.concat(memory)
             t_tr = time.time()
-            losses = []
+            losses, epoch_means = [], []
             for ep in range(self.config.num_epochs):                            # :78-81
-                losses += self.train(mem, resident=ep > 0)
+                ep_losses = self.train(mem, resident=ep > 0)
+                losses += ep_losses
+                # the signal of an epoch is its MEAN loss: the last step of an epoch is the reference's partial batch
+                # (n mod training_batch_size samples, alphazero.rs:205-206 -- 4 samples in the full-size configs[4] run)
+                epoch_means.append(float(np.mean(ep_losses)) if ep_losses else None)
             self.sync_engine()
             t_tr = time.time() - t_tr
             if self.rank == 0:
@@ -550,11 +554,14 @@ class AlphaZero:
                 os.makedirs(mdir, exist_ok=True)
                 np.save(os.path.join(mdir, f"model_{l_i}.npy"), self.blob)      # :85-95
                 self.log(f"Iteration {l_i} saved successfully; {len(mem['outcome'])} fragments, self-play {t_sp:.1f} s, "
-                         f"train {t_tr:.1f} s, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+                         f"train {t_tr:.1f} s, loss {losses[0]:.4f} -> {losses[-1]:.4f}, epoch means "
+                         + " ".join(f"{m:.4f}" for m in epoch_means))
+            t_ar = time.time()
             verdict = self.play_vs_best_model(n_games=arena_games) if arena and self.rank == 0 else None   # :96
-            report.append({"learn_iteration": l_i, "fragments": len(mem["outcome"]), "self_play_s": t_sp, "train_s": t_tr,
+            t_ar = time.time() - t_ar
+            report.append({"learn_iteration": l_i, "fragments": len(mem["outcome"]), "self_play_s": t_sp, "train_s": t_tr, "arena_s": t_ar,
                            "loss_first": losses[0] if losses else None, "loss_last": losses[-1] if losses else None,
-                           "arena": verdict})
+                           "epoch_loss_means": epoch_means, "train_steps": len(losses), "arena": verdict})
         return report
 
     # ---- play_vs_best_model / play_vs_model, alpha_versus.rs:16-81 ----

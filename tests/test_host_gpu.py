@@ -65,17 +65,14 @@ def test_learn_iteration_smoke(oracle, tmp_path):
     eng.close()
 
 
-def test_learn_loop_at_config5_parameters_reduced_batch(tmp_path):
-    """BASELINE configs[4] at its stated parameter values -- learn_iterations=2, self_play_iterations=4, num_epochs=4,
-    training_batch_size=256, iterations=100, temperature 1.25, arena of 400 games -- with num_self_play_batches reduced from 1024
-    to 64 (a 1024-game run takes minutes: bench.py --learn-loop / scripts/learn_config5.py): both learn iterations run every
-    phase (4 pipelined self-play batches, cumulative sp-j dirs, 4 epochs of fp32 training, fold-back, arena vs best_model) and the
-    wall clock per phase is printed"""
+def _config5_loop(tmp_path, games, label):
+    """the learn loop at BASELINE configs[4]'s parameter values with `games` games per self-play batch: runs every phase of both
+    learn iterations, prints the wall clock per phase, returns the report"""
     import time
     import diee_amd
     eng = diee_amd.Engine(0)
     conf = az.AlphaZeroConfig(temperature=1.25, learn_iterations=2, self_play_iterations=4, num_epochs=4,
-                              training_batch_size=256, num_self_play_batches=64)
+                              training_batch_size=256, num_self_play_batches=games)
     a = az.AlphaZero(eng, conf, diee_amd.MctsConfig.default(100), az.OptimizerParams(1e-4, 1e-3), blob=diee_amd.random_weights(0),
                      root=str(tmp_path), quiet=True)
     assert a.train_backend == "fp32"                                             # the reference's arithmetic is the default
@@ -84,19 +81,52 @@ def test_learn_loop_at_config5_parameters_reduced_batch(tmp_path):
     total = time.time() - t
     assert len(rep) == 2
     for r in rep:
-        assert r["fragments"] > 4 * 64 * 40 and np.isfinite(r["loss_last"]) and r["loss_last"] < r["loss_first"]
-        print(f"[config5, 64 games per batch] learn iteration {r['learn_iteration']}: {r['fragments']} fragments, self-play {r['self_play_s']:.1f} s, "
-              f"train {r['train_s']:.1f} s, loss {r['loss_first']:.3f} -> {r['loss_last']:.3f}, arena: {r['arena']}")
-    print(f"[config5, 64 games per batch] whole loop {total:.1f} s")
+        means = r["epoch_loss_means"]
+        # The signal: the MEAN loss of an epoch.  (The last step of an epoch is the reference's partial batch, alphazero.rs:205-206:
+        # n mod 256 samples -- 4 in the full-size run, whose single-step loss says nothing.)  Training descends over the four epochs
+        # of a learn iteration, and every epoch mean sits below the iteration's very first step (a random-init net: ~12).
+        assert len(means) == 4 and all(np.isfinite(m) for m in means)
+        assert means[-1] < means[0], means
+        assert r["train_steps"] == 4 * -(-r["fragments"] // 256)
+        print(f"[config5, {label}] learn iteration {r['learn_iteration']}: {r['fragments']} fragments, self-play {r['self_play_s']:.1f} s, "
+              f"train {r['train_s']:.1f} s ({r['train_steps']} steps), arena {r['arena_s']:.1f} s, epoch mean loss "
+              + " -> ".join(f"{m:.3f}" for m in means) + f", arena: {r['arena']}")
+    assert rep[0]["epoch_loss_means"][-1] < rep[0]["loss_first"]
+    print(f"[config5, {label}] whole loop {total:.1f} s")
     assert rep[0]["arena"] == "saved-as-best"
     assert rep[1]["arena"] in ("new model was better!", "current best model is still better!",
                                "new model vs current best was inconclusive, keeping current best!")
     run = next((tmp_path / "data" / "backgammon").iterdir())
     for li in range(2):
-        sizes = [len(az.AlphaZero.load_training_data(str(run / f"lrn-{li}" / f"sp-{j}"))["outcome"]) for j in range(4)]
+        dirs = [run / f"lrn-{li}" / f"sp-{j}" for j in range(4)]
+        sizes = [len(np.load(d / "outcomes.npy", mmap_mode="r")) for d in dirs]
         assert sizes == sorted(sizes) and sizes[0] > 0 and sizes[3] == rep[li]["fragments"]      # cumulative memory per sp dir (Q20)
+        assert all(np.load(d / "ps.npy", mmap_mode="r").shape == (n, 1352) and np.load(d / "states.npy", mmap_mode="r").shape == (n, 6, 4, 6)
+                   for d, n in zip(dirs, sizes))                                                  # alphazero.rs:149-200
         assert (tmp_path / "models" / "backgammon" / f"model_{li}.npy").exists()
     eng.close()
+    return rep, total
+
+
+def test_learn_loop_at_config5_parameters_reduced_batch(tmp_path):
+    """BASELINE configs[4] at its stated parameter values with num_self_play_batches reduced from 1024 to 64 (the quick case;
+    the full size is the next test): both learn iterations run every phase (4 pipelined self-play batches, cumulative sp-j dirs,
+    4 epochs of fp32 training, fold-back, arena vs best_model)"""
+    rep, _ = _config5_loop(tmp_path, 64, "64 games per batch")
+    assert all(r["fragments"] > 4 * 64 * 40 for r in rep)
+
+
+def test_learn_loop_config5_full_size(tmp_path):
+    """BASELINE configs[4] AT ITS OWN SIZE on one GPU: learn_iterations=2, self_play_iterations=4, num_epochs=4,
+    training_batch_size=256, num_self_play_batches=1024, iterations=100, temperature 1.25, arena of 400 games, the default fp32
+    training step (alpha_parallel.rs:17-99, alphazero.rs:202-261).  ~5 minutes: 2 x (4 batches of 1024 games side by side,
+    ~430 k / ~640 k cumulative fragments written per sp-j dir, 4 epochs of ~1 700 / ~2 500 steps, fold-back, arena)."""
+    rep, total = _config5_loop(tmp_path, 1024, "1024 games per batch = configs[4]")
+    assert all(r["fragments"] > 4 * 1024 * 60 for r in rep)                      # ~105 records per game
+    # the second learn iteration trains the first one's network on fresh games: it starts far below a random-init network's loss
+    assert rep[1]["epoch_loss_means"][0] < rep[0]["epoch_loss_means"][0]
+    import shutil
+    shutil.rmtree(tmp_path / "data", ignore_errors=True)                         # ~16 GB of cumulative sp-j dirs
 
 
 def test_cli_end_to_end_in_a_child_process(tmp_path):
