@@ -10,27 +10,48 @@ What the reference writes (src/alphazero/alphazero.rs:149-200,263-265; src/alpha
   * training data: `Tensor::save(path)` = `torch::save(tensor, path)`: the same kind of archive with the single key "0"
     (`ps.ot [M,1352]`, `states.ot [M,6,4,6]`, `outcomes.ot [M]` i8).
 
-PARITY UNPINNED: the reference ships no `.ot` file and tch is not vendored, so the exact variable names and the within-
-layer creation order (weight-before-bias or the reverse) cannot be checked here.  Reading is therefore tolerant: tensors are
-ordered by their `__N` suffix (creation order) and matched to the architecture by base name and shape, whichever order a
-layer's variables were created in.  Writing uses the order stated above; `tests/test_host_cpu.py` round-trips archives
-this module wrote itself.
+PINNED TO LIBTORCH'S OWN SERIALIZER (round 5): `oracle/ot_ref/ot_tool.cpp` (test infrastructure) makes exactly the four
+libtorch calls tch's C shim makes -- `OutputArchive::write(name, tensor)` + `save_to`, `torch::save(tensor)`,
+`jit::load(..).named_parameters()`, `torch::load(tensor)` -- against the libtorch inside this image's PyTorch wheel;
+`tests/test_host_cpu.py` reads archives that program wrote (small ones committed under `tests/golden/ot/`) bit-exactly and has
+that program read what this module writes.  So the CONTAINER FORMAT is pinned in both directions.
+
+STILL RECALLED, NOT PINNED: the reference ships no `.ot` file and tch is not vendored, so the variable NAMES tch generates
+(`weight`, `bias`, `weight__N`) and the within-layer creation order (weight-before-bias or the reverse) cannot be checked
+here.  Reading is therefore tolerant: tensors are ordered by their `__N` suffix (creation order) and matched to the
+architecture by base name and shape, whichever order a layer's variables were created in and whatever order the archive lists
+them in (tch saves a HashMap's iteration order).  Writing uses the order stated above.
 """
 import re
 
 import numpy as np
 import torch
 
-F, BLOCKS, A, CIN = 256, 19, 1352, 6
+# (filters, blocks, actions, input planes, board cells): Backgammon (backgammon_logic.rs:74-78) and TicTacToe (tictactoe/mod.rs:20-24)
+BACKGAMMON_ARCH = (256, 19, 1352, 6, 24)
+TICTACTOE_ARCH = (64, 4, 9, 3, 9)
+ARCHS = (BACKGAMMON_ARCH, TICTACTOE_ARCH)
 
 
-def _layers():
+def _layers(arch=BACKGAMMON_ARCH):
     """the layers in creation order (nnet.rs:62-97; ResBlock::new nnet.rs:38-45: conv1, conv2, bn1, bn2)"""
+    F, BLOCKS, A, CIN, HW = arch
     L = [("conv", F, CIN), ("bn", F)]
     for _ in range(BLOCKS):
         L += [("conv", F, F), ("conv", F, F), ("bn", F), ("bn", F)]
-    L += [("conv", 32, F), ("bn", 32), ("fc", A, 768), ("conv", 3, F), ("bn", 3), ("fc", 1, 72)]
+    L += [("conv", 32, F), ("bn", 32), ("fc", A, 32 * HW), ("conv", 3, F), ("bn", 3), ("fc", 1, 3 * HW)]
     return L
+
+
+def weights_count(arch):
+    return sum(int(np.prod(shape)) for layer in _layers(arch) for _, shape in _layer_tensors(layer))
+
+
+def arch_of_blob(blob):
+    for arch in ARCHS:
+        if weights_count(arch) == np.size(blob):
+            return arch
+    raise ValueError(f"a blob of {np.size(blob)} floats is neither game's ResNet")
 
 
 def _layer_tensors(layer):
@@ -72,10 +93,10 @@ def _load_named(path):
 
 # --------------------------------------------------------------------------- models
 def blob_to_named(blob):
-    """flat fp32 blob (include/diee.h order) -> [(VarStore name, tensor)] in creation order"""
+    """flat fp32 blob (include/diee.h order; either game's network, told by its size) -> [(VarStore name, tensor)] in creation order"""
     blob = np.ascontiguousarray(blob, dtype=np.float32)
     named, seen, off = [], set(), 0
-    for layer in _layers():
+    for layer in _layers(arch_of_blob(blob)):
         parts = {}
         for base, shape in _layer_tensors(layer):
             n = int(np.prod(shape))
@@ -88,8 +109,12 @@ def blob_to_named(blob):
     return named
 
 
-def named_to_blob(named):
-    """[(name, tensor)] of a VarStore archive -> flat fp32 blob; tolerant to the within-layer creation order"""
+def named_to_blob(named, arch=None):
+    """[(name, tensor)] of a VarStore archive -> flat fp32 blob; tolerant to the within-layer creation order and to the order the
+    archive lists its tensors in.  arch None: told by the number of tensors (250 backgammon, 70 tic-tac-toe)"""
+    if arch is None:
+        arch = next((a for a in ARCHS if sum(len(_layer_tensors(l)) for l in _layers(a)) == len(named)), BACKGAMMON_ARCH)
+
     def key(item):
         m = re.fullmatch(r"(.+?)__(\d+)", item[0])
         return int(m.group(2)) if m else -1          # un-suffixed names were created first (one per base name)
@@ -97,7 +122,7 @@ def named_to_blob(named):
     used = [False] * len(entries)
     out = []
     cursor = 0
-    for layer in _layers():
+    for layer in _layers(arch):
         want = _layer_tensors(layer)
         got = {}
         # the layer's variables are the next len(want) unused entries in creation order; match them by name and shape

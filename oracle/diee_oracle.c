@@ -675,6 +675,7 @@ struct or_mcts_run {
     uint32_t it;
 };
 
+static or_mcts_run* g_last_run = NULL;      /* trace tools only (or_mcts_last) */
 or_mcts_run* or_mcts_begin(const or_game* g, or_store* st, const or_state* states, int n, const or_mcts_cfg* cfg,
                            uint64_t seed, uint32_t step, const uint32_t* game_ids, const uint32_t* rounds,
                            int ref_quirks, or_stats* stats) {
@@ -688,11 +689,18 @@ or_mcts_run* or_mcts_begin(const or_game* g, or_store* st, const or_state* state
     r->fresh = malloc((size_t)(n > 0 ? n : 1));
     r->noise = malloc(sizeof(float) * (size_t)g->n_actions);
     r->phase = 0; r->it = 0;
+    g_last_run = r;
     return r;
 }
 const or_state* or_mcts_batch(const or_mcts_run* r) { return r->batch; }
 int or_mcts_rows(const or_mcts_run* r) { return r->n; }
-void or_mcts_end(or_mcts_run* r) { free(r->batch); free(r->sel); free(r->fresh); free(r->noise); free(r); }
+/* read-only views of a run between or_mcts_next() and or_mcts_feed() (scripts/spec_price.py replays searches from them) */
+or_mcts_run* or_mcts_last(void) { return g_last_run; }
+const int* or_mcts_sel(const or_mcts_run* r) { return r->sel; }
+const uint8_t* or_mcts_fresh(const or_mcts_run* r) { return r->fresh; }
+int or_mcts_phase(const or_mcts_run* r) { return r->phase ? 1 + (int)r->it : 0; }
+const or_store* or_mcts_store(const or_mcts_run* r) { return r->st; }
+void or_mcts_end(or_mcts_run* r) { if (g_last_run == r) g_last_run = NULL; free(r->batch); free(r->sel); free(r->fresh); free(r->noise); free(r); }
 
 int or_mcts_next(or_mcts_run* r) {
     if (r->phase == 0) return OR_MCTS_EVAL;                                /* :97-104 forward_policy of the roots */

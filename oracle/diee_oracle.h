@@ -171,6 +171,13 @@ int  or_mcts_next(or_mcts_run* r);
 const or_state* or_mcts_batch(const or_mcts_run* r);
 int  or_mcts_rows(const or_mcts_run* r);
 void or_mcts_feed(or_mcts_run* r, float* policy, const float* value);
+/* read-only views for trace tools, valid inside the evaluator callback: the run begun last (single-threaded use), its
+ * selected_nodes_idxs, which of them were selected in this iteration, 0 = roots pending / 1 + it, and its node store */
+or_mcts_run* or_mcts_last(void);
+const int* or_mcts_sel(const or_mcts_run* r);
+const uint8_t* or_mcts_fresh(const or_mcts_run* r);
+int  or_mcts_phase(const or_mcts_run* r);
+const or_store* or_mcts_store(const or_mcts_run* r);
 void or_mcts_end(or_mcts_run* r);
 /* get_prob_tensor_parallel, utils.rs:42-58: probs[n][A] */
 void or_get_prob_tensor_parallel(const or_game* g, const or_store* st, int n, float* probs);
