@@ -275,7 +275,9 @@ def main(argv=None, engine_factory=None):
     """argv / engine_factory: tests/test_dist_cpu.py drives this very function on gloo ranks with a stand-in engine
     (DIEE_BENCH_BACKEND=gloo: CPU tensors for the reductions, no torch.cuda call); the driver and users run it as a script."""
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="the job's size = WORLD_SIZE of the launcher (checked); N > 1: python -m torch.distributed.run ...")
+    ap.add_argument("--share-lock", default=None, help="tests: ranks that share one GPU keep the full kernel set and take turns through this lock file "
+                    "(default for shared GPUs: diee_set_option shared_gpu = 1)")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--config", type=int, choices=sorted(PRESETS), default=1, help="BASELINE.json configs[] preset: 1 = 1024 games x iterations 100 "
@@ -309,11 +311,17 @@ def main(argv=None, engine_factory=None):
     import importlib
     ddist = importlib.import_module("die-e_amd.dist")
     rank, local_rank, world = ddist.rank_world()
+    if args.gpus != world:
+        # `--gpus N` names the job size; the ranks come from the launcher (python -m torch.distributed.run --nproc-per-node N ...).
+        # Alone, `python bench.py --gpus 8` would run ONE rank and report n_gpus = 1 under an 8-GPU flag: refuse instead.
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     backend = os.environ.get("DIEE_BENCH_BACKEND", "nccl")      # "gloo": the CPU test of this function
     red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     dev = local_rank
     affinity = None
+    shares_gpu = False                           # ranks really share a GPU (tests; never on the 8-GPU node)
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch
         import torch.distributed as dist
@@ -329,23 +337,51 @@ def main(argv=None, engine_factory=None):
             dev = local_rank % ndev
             if world > ndev and not narrowed:
                 # ranks really share a GPU: the small-batch cluster tower needs its workgroups resident together,
-                # which two processes on one GPU cannot promise each other
-                os.environ["DIEE_TOWER_CL"] = "none"
-                os.environ["DIEE_TOWER_PAIR"] = "0"     # (the pair tower hands over inside its launch too)
-                os.environ["DIEE_BN_COOP"] = "0"
+                # which two processes on one GPU cannot promise each other: told to the engine
+                # below through its ABI (diee_set_option "shared_gpu"), not through the environment
+                shares_gpu = True
             torch.cuda.set_device(dev)             # torch's HIP runtime initialises before libdiee.so's
             if world > 1:
                 affinity = pin_to_gpu_numa(torch, dev)
         dist.init_process_group(backend)           # "nccl" is RCCL on ROCm
 
     import diee_amd
+    pci = None
+    if dist is not None and backend == "nccl" and engine_factory is None:
+        # two HIP runtimes live in this process (PyTorch's bundled one and the system one behind libdiee.so): before the engine is
+        # created, make sure both mean the same GPU by ordinal `dev` -- a mismatch would time the engine on another rank's GPU
+        ok, ours, theirs = diee_amd.same_gpu_as_torch(dev)
+        pci = ours
+        if not ok:
+            raise SystemExit(f"bench.py rank {rank}: device {dev} is {ours} for libdiee.so but {theirs} for torch: the two HIP runtimes "
+                             "enumerate the GPUs differently (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set for one of them only?)")
     eng = (engine_factory or diee_amd.Engine)(dev)   # raises without a GPU: there is no CPU path
+    share_lock = None
+    if shares_gpu and hasattr(eng, "set_option"):
+        if args.share_lock:
+            # test mode (tests/test_dist_gpu.py): the ranks keep the kernel set a GPU of their own would run -- in-launch hand-overs
+            # included -- and take turns on the shared GPU through an exclusive lock around every engine call
+            import fcntl
+            share_lock = open(args.share_lock, "a+")
+        else:
+            eng.set_option("shared_gpu", 1)
+            diee_amd.load_library().diee_train_set_bn_coop(0)
     eng.load_weights(diee_amd.random_weights(0))
+
+    class _Turn:                                     # the shared-GPU lock of --share-lock; a no-op otherwise
+        def __enter__(self):
+            if share_lock is not None:
+                fcntl.flock(share_lock, fcntl.LOCK_EX)
+        def __exit__(self, *a):
+            if share_lock is not None:
+                fcntl.flock(share_lock, fcntl.LOCK_UN)
+    turn = _Turn()
     cfg = diee_amd.MctsConfig(iterations=args.iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     first_id = ddist.shard_first_game_id(rank, args.games)
     # primer (not a step): pages in the code objects, sizes the HBM arenas and pins the host blocks the records land in
-    o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=True, copy=False)
-    o.get("free", lambda: None)()
+    with turn:
+        o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed, first_game_id=first_id, max_steps=1, fetch=True, copy=False)
+        o.get("free", lambda: None)()
 
     def barrier():
         if dist is not None:
@@ -358,8 +394,9 @@ def main(argv=None, engine_factory=None):
         """one self_play_parallel call as a host binding the C ABI makes it: the call returns with the MemoryFragments in
         engine-owned host arrays (fetch) -- looked at, handed back -- or with the records left in HBM (the HBM-only leg)"""
         t = time.perf_counter()
-        o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
-                                   first_game_id=first_id, fetch=fetch, copy=False, max_steps=args.max_steps)
+        with turn:
+            o = eng.self_play_parallel(args.games, cfg, 1.25, args.seed + 0x9E37 * i, ref_quirks=True,
+                                       first_game_id=first_id, fetch=fetch, copy=False, max_steps=args.max_steps)
         st = o["stats"]
         if fetch:
             assert len(o["outcome"]) == st["fragments"] and o["ps"].shape == (st["fragments"], 1352), "delivered records != counted records"
@@ -403,11 +440,13 @@ def main(argv=None, engine_factory=None):
     if args.pipeline > 1:
         K = args.pipeline
         batches = [(args.games, first_id, args.seed + 0x9E37 * i) for i in range(K)]
-        for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, max_steps=1, fetch=True, copy=False):      # sizes the arenas
-            o.get("free", lambda: None)()
+        with turn:
+            for o in eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, max_steps=1, fetch=True, copy=False):      # sizes the arenas
+                o.get("free", lambda: None)()
         barrier()
         tp0 = time.perf_counter()
-        outs = eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=True, copy=False, max_steps=args.max_steps)
+        with turn:
+            outs = eng.self_play_multi(batches, cfg, 1.25, ref_quirks=True, fetch=True, copy=False, max_steps=args.max_steps)
         sts = [o["stats"] for o in outs]
         for o in outs:
             o.get("free", lambda: None)()
@@ -425,7 +464,16 @@ def main(argv=None, engine_factory=None):
             "fragments", "illegal_decodes", "deliver_seconds", "deliver_bytes"]
     keys += [f"{n}.{b}" for n in ("band_seconds", "band_launches", "band_flops") for b in range(len(BAND_NAMES))]
     frags_per_rank = [int(tot.get("fragments", 0))]
+    # every rank's own rate over the shared clock window (games it retired / its own time inside the K calls): a straggler shows here
+    own_s = sum(step_s)
+    rank_values = [round(tot.get("games", 0) / own_s, 3) if own_s > 0 else 0.0]
+    rank_pci = [pci]
     if dist is not None:
+        rank_values = [v / 1000.0 for v in ddist.gather_counts(dist, int(rank_values[0] * 1000), red_dev)]
+        if pci is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, pci)
+            rank_pci = gathered
         # after a self-play batch the ranks all-gather their fragment counts (8 x u64 on a node) -- what a
         # consumer of the sharded records (the learn loop's trainer) needs to size its receive buffers; the records stay put
         frags_per_rank = ddist.gather_counts(dist, frags_per_rank[0], red_dev)
@@ -553,6 +601,8 @@ def main(argv=None, engine_factory=None):
                       "tree_bytes_per_search": 56 * (tot["children"] / max(tot["plies"], 1) + 1),
                       "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64)},
             "roofline": dominant, "roofline_other": other,
+            "value_per_rank": rank_values,           # games/s of each rank by its own clock (value = all games / the slowest rank's window)
+            "pci_bus_id_per_rank": rank_pci,         # libdiee.so's GPU per rank, checked against torch's before the engine was created (N > 1)
             "fragments_per_rank": frags_per_rank,    # all_gather of the per-rank record counts; the records stay on their rank
         }
         # what the delivery of the records costs: the same batches (same seeds) with the records left in HBM

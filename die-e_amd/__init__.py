@@ -44,7 +44,7 @@ assert TTT_STATE.itemsize == 32
 # every symbol include/diee.h declares (checked by the CPU test-suite against the built library); the development probes
 # of include/diee_dev.h are listed in DEV_EXPORTS
 EXPORTS = [
-    "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_weights_count",
+    "diee_create", "diee_destroy", "diee_last_error", "diee_version", "diee_set_option", "diee_get_option", "diee_device_pci_bus_id", "diee_weights_count",
     "diee_random_weights", "diee_load_weights", "diee_nn_forward", "diee_mcts_batch", "diee_self_play",
     "diee_self_play_multi", "diee_set_invariant_nn", "diee_train_pack_conv3x3", "diee_train_pack_conv3x3_multi",
     "diee_train_conv3x3", "diee_train_im2col3x3",
@@ -127,6 +127,9 @@ def load_library(path=None):
     L.diee_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]; L.diee_create.restype = C.c_int
     L.diee_destroy.argtypes = [vp]; L.diee_destroy.restype = None
     L.diee_last_error.argtypes = [vp]; L.diee_last_error.restype = C.c_char_p
+    L.diee_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]; L.diee_device_pci_bus_id.restype = C.c_int
+    L.diee_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]; L.diee_set_option.restype = C.c_int
+    L.diee_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]; L.diee_get_option.restype = C.c_int
     L.diee_weights_count.argtypes = [C.c_int]; L.diee_weights_count.restype = C.c_size_t
     L.diee_random_weights.argtypes = [C.c_int, u64, vp, C.c_size_t]; L.diee_random_weights.restype = C.c_int
     L.diee_load_weights.argtypes = [vp, vp, C.c_size_t]; L.diee_load_weights.restype = C.c_int
@@ -167,6 +170,26 @@ def load_library(path=None):
     if path is None:
         _lib = L
     return L
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of the GPU libdiee.so's HIP runtime calls `device` (diee_device_pci_bus_id)"""
+    buf = C.create_string_buffer(64)
+    st = load_library().diee_device_pci_bus_id(device, buf, 64)
+    if st != OK:
+        raise DieeError(st, f"diee_device_pci_bus_id({device})")
+    return buf.value.decode()
+
+
+def same_gpu_as_torch(device):
+    """(ok, engine's PCI address, torch's) for ordinal `device`: the two HIP runtimes of a PyTorch process must mean the same GPU by it"""
+    import torch
+    pr = torch.cuda.get_device_properties(device)
+    ours = device_pci_bus_id(device).lower()
+    if not hasattr(pr, "pci_bus_id"):
+        return True, ours, None
+    theirs = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+    return ours == theirs, ours, theirs
 
 
 def weights_count(game_id=GAME_BACKGAMMON):
@@ -221,6 +244,22 @@ class Engine:
     def _chk(self, st):
         if st != OK:
             raise DieeError(st, self._L.diee_last_error(self._h).decode())
+
+    # ---- options of the ctx (diee_set_option: what used to be DIEE_* environment switches) ----
+    def set_option(self, key, value):
+        """e.g. set_option("shared_gpu", 1) when several processes compute on this GPU; include/diee.h lists the keys"""
+        self._chk(self._L.diee_set_option(self._h, str(key).encode(), str(value).encode()))
+        return self
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            self.set_option(k, v)
+        return self
+
+    def get_option(self, key):
+        buf = C.create_string_buffer(256)
+        self._chk(self._L.diee_get_option(self._h, str(key).encode(), buf, 256))
+        return buf.value.decode()
 
     # ---- LearnableGame trait, batched -------------------------------------------------------
     def get_valid_moves(self, states, cap=256):

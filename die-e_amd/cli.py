@@ -124,6 +124,7 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = local_rank
+    shares_gpu = False
     if world > 1:
         # under torch.distributed.run: one rank per GPU.  torch picks its device and RCCL comes up BEFORE the engine
         # touches the GPU (torch's HIP runtime has to initialise first; nothing is re-exec'ed afterwards)
@@ -132,14 +133,16 @@ def main(argv=None):
         ndev = max(torch.cuda.device_count(), 1)
         device = local_rank % ndev
         if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
-            os.environ["DIEE_TOWER_CL"] = "none"       # ranks share a GPU: no in-launch hand-overs between co-resident grids
-            os.environ["DIEE_TOWER_PAIR"] = "0"        # (the pair tower hands over inside its launch too)
-            os.environ["DIEE_BN_COOP"] = "0"           # ... in the training step's BatchNorm passes either
+            shares_gpu = True                          # ranks share a GPU: told to the engine below (diee_set_option "shared_gpu")
         if torch.cuda.is_available():
             torch.cuda.set_device(device)
         if not dist.is_initialized():
             dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     eng = Engine(device)
+    if shares_gpu:
+        from . import load_library
+        eng.set_option("shared_gpu", 1)                # no in-launch hand-overs between co-resident grids (cluster / pair tower) ...
+        load_library().diee_train_set_bn_coop(0)       # ... nor in the training step's BatchNorm passes
     if args.command == "learn":                                                               # main.rs:121-124
         az = AlphaZero.from_config(eng, conf, model_path=args.model_path, rank=rank, world=world,
                                    train_device=(f"cuda:{device}" if world > 1 else None))

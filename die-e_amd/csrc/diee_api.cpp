@@ -84,6 +84,31 @@ void diee_destroy(diee_ctx* c) { delete c; }
 
 const char* diee_last_error(const diee_ctx* c) { return c ? c->err : "null ctx"; }
 
+diee_status diee_device_pci_bus_id(int device, char* out, size_t cap) {
+    if (!out || cap < 16) return DIEE_ERR_ARG;
+    out[0] = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DIEE_ERR_HIP;
+    if (hipDeviceGetPCIBusId(out, (int)cap, device) != hipSuccess) { out[0] = 0; return DIEE_ERR_HIP; }
+    return DIEE_OK;
+}
+
+diee_status diee_set_option(diee_ctx* c, const char* key, const char* value) {
+    API_BEGIN(c)
+    if (!key || !value) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    bg(c)->set_option(key, value);
+    API_END(c)
+}
+
+diee_status diee_get_option(diee_ctx* c, const char* key, char* value, size_t cap) {
+    API_BEGIN(c)
+    if (!key || !value || !cap) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    const std::string v = bg(c)->get_option(key);
+    if (v.size() + 1 > cap) throw EngineError(DIEE_ERR_ARG, "value buffer too small");
+    memcpy(value, v.c_str(), v.size() + 1);
+    API_END(c)
+}
+
 diee_status diee_bg_legal_moves(diee_ctx* c, const diee_bg_state* s, uint32_t n, int8_t* plays, uint32_t cap,
                                 uint32_t* counts) {
     API_BEGIN(c)

@@ -1,6 +1,8 @@
 // engine.cpp -- Engine construction and the pure game functions.
 #include "engine.h"
 
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -13,9 +15,92 @@ void cluster_baton_register(int device, int delta);
 void nn_reset_cluster(Engine& e);
 void nn_disable_cluster(Engine& e);
 void free_search(SearchBufs*);
+void pinned_pool_set_cap_mb(size_t mb);
+size_t pinned_pool_cap_mb();
+
+// ---- options ---------------------------------------------------------------------------------------------------------
+namespace {
+struct OptEntry { const char* key; int Options::*i; uint32_t Options::*u; std::string Options::*s; };
+const OptEntry kOptions[] = {
+    {"tower_table", nullptr, nullptr, &Options::tower_table}, {"tower_cl", nullptr, nullptr, &Options::tower_cl},
+    {"tower_pair", &Options::tower_pair, nullptr, nullptr}, {"fused_heads", &Options::fused_heads, nullptr, nullptr},
+    {"cluster_heads", &Options::cluster_heads, nullptr, nullptr}, {"cluster_init", &Options::cluster_init, nullptr, nullptr},
+    {"compact", &Options::compact, nullptr, nullptr}, {"cl_pack", &Options::cl_pack, nullptr, nullptr},
+    {"shared_gpu", &Options::shared_gpu, nullptr, nullptr},
+    {"cl_grow", &Options::cl_grow, nullptr, nullptr}, {"expand2", &Options::expand2, nullptr, nullptr},
+    {"expand2c", &Options::expand2c, nullptr, nullptr}, {"split_expand", &Options::split_expand, nullptr, nullptr},
+    {"fc_grow", &Options::fc_grow, nullptr, nullptr}, {"spec_eval", &Options::spec_eval, nullptr, nullptr},
+    {"path_cap", nullptr, &Options::path_cap, nullptr}, {"nodes_per_expansion", nullptr, &Options::nodes_per_expansion, nullptr},
+    {"deliver_stage_rows", nullptr, &Options::deliver_stage_rows, nullptr}, {"deliver_rows_per_game", nullptr, &Options::deliver_rows_per_game, nullptr},
+    {"trace_steps", &Options::trace_steps, nullptr, nullptr}, {"trace_dispatch", &Options::trace_dispatch, nullptr, nullptr},
+    {"test_starve_at", &Options::test_starve_at, nullptr, nullptr},
+    {"pinned_pool_mb", nullptr, nullptr, nullptr},          // process-wide: the cap of the pool of page-locked output blocks (search_host.cpp)
+};
+const OptEntry* find_option(const std::string& key) {
+    for (const auto& e : kOptions) if (key == e.key) return &e;
+    return nullptr;
+}
+bool parse_num(const std::string& v, long long& out) {
+    if (v.empty()) return false;
+    char* end = nullptr;
+    out = strtoll(v.c_str(), &end, 10);
+    return end && *end == 0;
+}
+// "a:b,c:d" | "none" | "default"
+bool table_ok(const std::string& v) {
+    if (v == "none" || v == "default") return true;
+    size_t pos = 0;
+    while (pos < v.size()) {
+        const size_t c = v.find(':', pos), e = v.find(',', pos);
+        long long a, b;
+        if (c == std::string::npos || (e != std::string::npos && e < c)) return false;
+        if (!parse_num(v.substr(pos, c - pos), a) || !parse_num(v.substr(c + 1, (e == std::string::npos ? v.size() : e) - c - 1), b)) return false;
+        if (e == std::string::npos) return true;
+        pos = e + 1;
+    }
+    return false;
+}
+}  // namespace
+
+void Engine::set_option(const std::string& key, const std::string& value) {
+    const OptEntry* e = find_option(key);
+    if (!e) throw EngineError(DIEE_ERR_ARG, "unknown option `" + key + "`");
+    if (!e->s && !e->i && !e->u) {                          // pinned_pool_mb
+        long long v;
+        if (!parse_num(value, v) || v < 0) throw EngineError(DIEE_ERR_ARG, "option " + key + ": `" + value + "` is not a non-negative integer");
+        pinned_pool_set_cap_mb((size_t)v);
+        return;
+    }
+    if (e->s) {
+        if (!table_ok(value)) throw EngineError(DIEE_ERR_ARG, "option " + key + ": `" + value + "` is not \"a:b,c:d\", \"none\" or \"default\"");
+        opt.*(e->s) = value;
+    } else {
+        long long v;
+        if (!parse_num(value, v) || v < 0 || v > 0x7fffffffLL) throw EngineError(DIEE_ERR_ARG, "option " + key + ": `" + value + "` is not a non-negative integer");
+        if (e->i) opt.*(e->i) = (int)v; else opt.*(e->u) = (uint32_t)v;
+    }
+    apply_options();
+}
+
+std::string Engine::get_option(const std::string& key) const {
+    const OptEntry* e = find_option(key);
+    if (!e) throw EngineError(DIEE_ERR_ARG, "unknown option `" + key + "`");
+    if (!e->s && !e->i && !e->u) return std::to_string(pinned_pool_cap_mb());
+    if (e->s) return opt.*(e->s);
+    return std::to_string(e->i ? (long long)(opt.*(e->i)) : (long long)(opt.*(e->u)));
+}
 
 Engine::Engine(int dev) : device(dev) {
     err[0] = 0;
+    // the environment as a development override of the option defaults: read here, once per ctx, and nowhere else
+    for (const auto& e : kOptions) {
+        std::string name = "DIEE_";
+        for (const char* c = e.key; *c; ++c) name += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(name.c_str())) {
+            try { set_option(e.key, v); }
+            catch (const EngineError& x) { fprintf(stderr, "[diee] %s=%s ignored: %s\n", name.c_str(), v, x.what()); }
+        }
+    }
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     flags_dev.ensure(16);
@@ -44,7 +129,7 @@ void Engine::check_overflow() {
             // process (as the search paths do, cluster_starved), so the next call does not spin to the same timeout again
             nn_disable_cluster(*this);                      // also re-arms the hand-over counters
             throw EngineError(DIEE_ERR_HIP, "cluster / pair tower: a workgroup hand-over timed out (grid not co-resident: another process on this GPU?); "
-                                            "both are now off for this process -- set DIEE_TOWER_CL=none DIEE_TOWER_PAIR=0 to start without them");
+                                            "both are now off for this ctx -- diee_set_option(ctx, \"shared_gpu\", \"1\") starts without them");
         }
         throw EngineError(DIEE_ERR_CAPACITY, "device capacity overflow (sequence table / tree arena), flag=" + std::to_string(f));
     }

@@ -44,6 +44,29 @@ struct DevBuf {
 struct NetWeights;   // nn_host.cpp
 struct SearchBufs;   // search_host.cpp
 
+// Per-ctx switches (diee_set_option, include/diee.h).  Defaults here; the environment (DIEE_<KEY IN CAPITALS>, e.g. DIEE_TOWER_CL for
+// "tower_cl") is read ONCE, when the ctx is created, as a development override of these defaults; nothing reads it afterwards.
+struct Options {
+    // network dispatch (applied to NetWeights by Engine::apply_options)
+    std::string tower_table = "default";    // "min:geometry,..." | "none" | "default": fused / pair tower by live games (nn_host.h)
+    std::string tower_cl = "default";       // "max:boards,..."   | "none" | "default": cluster tower (<= 256 boards)
+    int tower_pair = 1;                     // pair tower (257 ... 512 and 129 ... 256 boards); 0: single-workgroup geometries
+    int fused_heads = 1, cluster_heads = 1, cluster_init = 1;   // head convs / init block inside the tower launches
+    int compact = 1;                        // above 256 live games evaluate only the slots that need it
+    int cl_pack = 1;                        // few clusters share few XCDs
+    int shared_gpu = 0;                     // another PROCESS uses this GPU: no kernel of this ctx waits for a co-resident workgroup
+                                            // (cluster and pair tower off; the caller's training step: diee_train_set_bn_coop(0))
+    // search
+    int cl_grow = 1, expand2 = 1, expand2c = 1, split_expand = 0, fc_grow = 0;
+    int spec_eval = 1;                      // speculative leaf evaluation in the free rows of small launches (search_host.cpp)
+    uint32_t path_cap = 64, nodes_per_expansion = 128;
+    // output delivery
+    uint32_t deliver_stage_rows = 16384, deliver_rows_per_game = 128;
+    // development traces on stderr
+    int trace_steps = 0, trace_dispatch = 0;
+    int test_starve_at = 0;                 // tests: the k-th hand-over check of this ctx reports a starved hand-over (0: never)
+};
+
 class Engine {
 public:
     char err[512];
@@ -86,6 +109,12 @@ public:
     }
     void sync() { HIPCHK(hipStreamSynchronize(stream)); }
     void check_overflow();
+
+    Options opt;
+    int starve_checks = 0;
+    void set_option(const std::string& key, const std::string& value);    // throws DIEE_ERR_ARG on an unknown key / malformed value
+    std::string get_option(const std::string& key) const;
+    void apply_options();                                                  // opt -> NetWeights (after load_weights, after set_option)
 
     DevBuf<uint8_t> tmp_a, tmp_b, tmp_c, tmp_d, tmp_e;
     DevBuf<uint32_t> flags_dev;      // [0] capacity-overflow flag

@@ -24,7 +24,6 @@ struct GrowReq { Tree T; Slots S; Segs G; uint32_t n, it; };
 
 // nn_kernels.hip
 void nn_setup_kernels();
-void nn_refresh_env();             // re-reads the per-launch development switches (DIEE_CL_PACK): once per search / API call, never beside a launch
 void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geometry (development)
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
 void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, const void* wpack, const float* bias,
@@ -44,7 +43,7 @@ constexpr int kClusterMaxGroups = 64;
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
                           const void* whead = nullptr, const float* bhead = nullptr, const void* wfc = nullptr, const float* bfc = nullptr,
-                          float* hv = nullptr, float* logits = nullptr, const GrowReq* grow = nullptr, bool* grown = nullptr);
+                          float* hv = nullptr, float* logits = nullptr, const GrowReq* grow = nullptr, bool* grown = nullptr, bool pack = true);
                           // grow: also grow the tree on extra workgroups if the whole grid stays resident (*grown tells)
 // train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 768 + 1280 floats of scratch)
 int train_stripes(int M);
@@ -84,7 +83,7 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 // mcts_kernels.hip
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
 void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks);
-struct ExpandVariant { bool two = true, two_c = true; };    // DIEE_EXPAND2 / DIEE_EXPAND2C, read by the caller once per search
+struct ExpandVariant { bool two = true, two_c = true; };    // options expand2 / expand2c
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown = false, ExpandVariant v = ExpandVariant{});   // next_it: iteration to select for afterwards, kNoNextIteration = none;
                                                                          // pre_grown: launch_grow(it) created the children already

@@ -142,48 +142,53 @@ void random_weights_bg(uint64_t seed, float* blob) {
 
 void free_net(NetWeights* n) { delete n; }
 
+// "a:b,c:d" -> pairs (validated by Engine::set_option)
+template <class Row>
+static void parse_table(const std::string& t, std::vector<Row>& out) {
+    out.clear();
+    size_t pos = 0;
+    while (pos < t.size() && t != "none") {
+        const size_t c = t.find(':', pos), e2 = t.find(',', pos);
+        if (c == std::string::npos) break;
+        out.push_back({atoi(t.substr(pos, c - pos).c_str()), atoi(t.substr(c + 1, (e2 == std::string::npos ? t.size() : e2) - c - 1).c_str())});
+        if (e2 == std::string::npos) break;
+        pos = e2 + 1;
+    }
+}
+
+// Options -> the network's dispatch state.  Called after load_weights, after every diee_set_option and when an in-launch hand-over
+// starved (NetWeights::starved): the one place that decides which tower kernels this ctx may launch.
+void Engine::apply_options() {
+    if (!net) return;
+    NetWeights& W = *net;
+    W.fused_heads = opt.fused_heads != 0; W.cluster_heads = opt.cluster_heads != 0; W.cluster_init = opt.cluster_init != 0;
+    W.compact = opt.compact != 0; W.cl_pack = opt.cl_pack != 0; W.trace_dispatch = opt.trace_dispatch != 0;
+    // kernels whose workgroups wait for each other INSIDE a launch (cluster tower, pair tower) need the GPU to themselves
+    const bool handoffs = !opt.shared_gpu && !W.starved;
+    bool pair = opt.tower_pair != 0 && handoffs;
+    if (pair && !tower_pair_device_ok(device)) {
+        // both members of a pair must be resident together and -- their hand-off stores are plain: they stay in the XCD's L2 -- on
+        // ONE XCD, which the kernel gets from blockIdx & 7 under round-robin dispatch to 8 XCDs; a device or partition that
+        // is not 8 XCDs x >= 32 CUs would spin every pair launch to its timeout before the (loud) fallback
+        pair = false;
+        if (!W.told_no_pair) fprintf(stderr, "[diee] pair tower: device %d is not 8 XCDs x 32 CUs (a partition?); using the single-workgroup geometries\n", device);
+        W.told_no_pair = true;
+    }
+    W.pair_tower = pair;
+    if (opt.tower_table == "default") W.tower_table = pair ? NetWeights::default_tower_table() : NetWeights::default_tower_table_no_pair();
+    else parse_table(opt.tower_table, W.tower_table);
+    if (!pair) for (auto& r : W.tower_table) if (r.geometry == 10 || r.geometry == 11) r.geometry = 3;      // (a table that names the pair tower)
+    if (!handoffs) W.cluster_table.clear();
+    else if (opt.tower_cl == "default") W.cluster_table = NetWeights::default_cluster_table();
+    else parse_table(opt.tower_cl, W.cluster_table);
+}
+
 void Engine::load_weights(const float* blob, size_t n) {
     HIPCHK(hipSetDevice(device));
     const BlobLayout& L = layout();
     if (n != L.total) throw EngineError(DIEE_ERR_ARG, "weight blob has " + std::to_string(n) + " floats, expected " + std::to_string(L.total));
     if (!net) { net = new NetWeights(); nn_setup_kernels(); }
-    if (const char* v = getenv("DIEE_FUSED_HEADS")) net->fused_heads = atoi(v) != 0;      // 0: head convs as their own launch behind the fused tower
-    if (const char* v = getenv("DIEE_TOWER_PAIR")) net->pair_tower = atoi(v) != 0;
-    if (net->pair_tower && !tower_pair_device_ok(device)) {
-        // both members of a pair must be resident together and -- their hand-off stores are plain: they stay in the XCD's L2 -- on
-        // ONE XCD, which the kernel gets from blockIdx & 7 under round-robin dispatch to 8 XCDs; a device or partition that
-        // is not 8 XCDs x >= 32 CUs would spin every pair launch to its timeout before the (loud) fallback
-        net->pair_tower = false;
-        fprintf(stderr, "[diee] pair tower: device %d is not 8 XCDs x 32 CUs (a partition?); using the single-workgroup geometries\n", device);
-    }
-    if (!net->pair_tower) net->tower_table = {{928, 5}, {640, 14}, {416, 6}, {256, 3}};
-    if (const char* v = getenv("DIEE_CLUSTER_HEADS")) net->cluster_heads = atoi(v) != 0;   // 0: head convs and policy FC as launches of their own behind the cluster tower
-    if (const char* v = getenv("DIEE_CLUSTER_INIT")) net->cluster_init = atoi(v) != 0;   // 0: init block as its own launch in front of the cluster tower   // 0: keep init block / heads as separate launches
-    if (const char* v = getenv("DIEE_COMPACT")) net->compact = atoi(v) != 0;               // 0: evaluate stale rows too, like the reference
-    if (const char* v = getenv("DIEE_TOWER_CL")) {         // development / tests: "max:boards,..." or "none"
-        net->cluster_table.clear();
-        std::string t(v);
-        size_t pos = 0;
-        while (pos < t.size() && t != "none") {
-            const size_t c = t.find(':', pos), e2 = t.find(',', pos);
-            if (c == std::string::npos) break;
-            net->cluster_table.push_back({atoi(t.substr(pos, c - pos).c_str()), atoi(t.substr(c + 1, (e2 == std::string::npos ? t.size() : e2) - c - 1).c_str())});
-            if (e2 == std::string::npos) break;
-            pos = e2 + 1;
-        }
-    }
-    if (const char* v = getenv("DIEE_TOWER_TABLE")) {      // development / tests
-        net->tower_table.clear();
-        std::string t(v);
-        size_t pos = 0;
-        while (pos < t.size() && t != "none") {
-            const size_t c = t.find(':', pos), e2 = t.find(',', pos);
-            if (c == std::string::npos) break;
-            net->tower_table.push_back({atoi(t.substr(pos, c - pos).c_str()), atoi(t.substr(c + 1, (e2 == std::string::npos ? t.size() : e2) - c - 1).c_str())});
-            if (e2 == std::string::npos) break;
-            pos = e2 + 1;
-        }
-    }
+    apply_options();
     NetWeights& W = *net;
     std::vector<float> w, b;
     std::vector<uint16_t> pk;
@@ -321,7 +326,7 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
                 else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
                 bool took = false;                                  // (an earlier chunk of this evaluation may have grown the tree already: only ever set)
                 const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took);
+                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack);
                 if (took) W.grow_done = true;
                 if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
                 return ok;
@@ -330,7 +335,7 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
         {
             bool took = false;
             const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                 whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took);
+                                                 whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack);
             if (took) W.grow_done = true;
             return ok;
         }
@@ -352,7 +357,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
     int tgeom = W.tower_geometry_for(G);
     if (tgeom < 0 && fused_family) tgeom = 3;                   // the remainder of a batch above 256 boards: never the split-K family
-    static const bool trace_dispatch = getenv("DIEE_TRACE_DISPATCH") != nullptr;      // development: which tower path a batch takes
+    const bool trace_dispatch = W.trace_dispatch;               // development: which tower path a batch takes
     // sampled timing of the tower: one HIP-event pair per sampled forward (per-launch pairs cost ~4.6 us each and
     // inflate a ~30 us kernel by 14 %; the chain amortises that to < 1 %)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -497,8 +502,8 @@ bool nn_cluster_used(Engine& e) {
 // per-layer kernels), clear the flag bit and re-arm the hand-over counters
 void nn_disable_cluster(Engine& e) {
     if (!e.net) return;
-    e.net->cluster_table.clear();
-    e.net->pair_tower = false; e.net->tower_table = {{928, 5}, {640, 14}, {416, 6}, {256, 3}};   // the pair tower hands over inside its launch too
+    e.net->starved = true;                  // the pair tower hands over inside its launch too: apply_options drops both
+    e.apply_options();
     uint32_t f = 0;
     e.d2h(&f, e.flags_dev.p, 1);
     e.sync();
@@ -643,7 +648,6 @@ void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* pol
     tmp_c.ensure((size_t)n * 4);
     h2d(tmp_a.p, (const uint8_t*)states, (size_t)n * 32);
     const int se = net->sample_every; net->sample_every = 0;
-    nn_refresh_env();
     nn_forward(*this, tmp_a.p, (int)n, (float*)tmp_b.p, (float*)tmp_c.p);
     net->sample_every = se;
     d2h((uint8_t*)policy, tmp_b.p, (size_t)n * 1352 * 4);

@@ -21,17 +21,23 @@ struct NetWeights {
     // Measured on MI355X (scripts/fwd_sweep*.py, scripts/tower_clock.py): 16x16x32 MFMA, 8 waves per workgroup (two per
     // SIMD: one wave's loads overlap the other's MFMAs: 79-81 % MFMA issue efficiency vs 62-67 % with one wave per SIMD),
     // 4 boards per workgroup above 416 boards (border-aware fragment order: 22 % of the MFMAs are padding and not issued;
-    // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  DIEE_TOWER_TABLE="min:geom,min:geom" overrides ("none" disables).
+    // 3 weight k-steps in flight above 928 boards, 6 below: within 1 % of each other), 2 boards above 256 (below that: the cluster tower).  option tower_table = "min:geom,min:geom" overrides ("none" disables).
     struct TowerRule { int min_games, geometry; };
     // Round 4: ONE wave per SIMD with four column fragments (geometry 5 = k_tower16<4,4,3>; 14 = the same code instantiated again for
     // the band below one pass of the chip) replaces the 8-wave geometries 8 / 6: half the A-fragment LDS reads at the same weight
     // traffic; its k loop is unrolled in full -- with the loop the accumulators (in AGPRs) were permuted across the back edge, 132
     // v_accvgpr moves per 18 k-steps, which is what "62-67 %" above measured: 603 vs 634 us at 1024 boards, 514 vs 531 at 768.
     // Below ~640 boards (fewer than 160 of 256 CUs busy: no power limit to give back to) the 8-wave geometry 6 is still the faster one.
-    std::vector<TowerRule> tower_table = {{928, 5}, {640, 14}, {512, 6}, {256, 10}, {128, 11}};     // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
+    static std::vector<TowerRule> default_tower_table() { return {{928, 5}, {640, 14}, {512, 6}, {256, 10}, {128, 11}}; }   // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
                                     // pair (257 ... 512 boards) / 2 boards per pair (129 ... 256: 277 ... 298 us against the cluster tower's 313 ... 318)
+    static std::vector<TowerRule> default_tower_table_no_pair() { return {{928, 5}, {640, 14}, {416, 6}, {256, 3}}; }   // option tower_pair = 0 / shared_gpu = 1
+    std::vector<TowerRule> tower_table = default_tower_table();      // option "tower_table" (Engine::apply_options)
     DevBuf<uint16_t> pair_ex;       // its exchange buffers (zeroed once)
-    bool pair_tower = true;         // DIEE_TOWER_PAIR=0: the 2-board geometry instead (rounds 1-2)
+    bool pair_tower = true;         // option "tower_pair" = 0: the 2-board geometry instead (rounds 1-2)
+    bool starved = false;           // an in-launch hand-over timed out in this ctx: cluster and pair tower stay off
+    bool told_no_pair = false;
+    bool cl_pack = true;            // option "cl_pack": few clusters share few XCDs (launch_tower_cluster)
+    bool trace_dispatch = false;    // option "trace_dispatch"
     bool invariant = false;         // DIEE_FLAG_INVARIANT_NN / diee_set_invariant_nn: every batch size on the fused 16x16x32 tower
     int tower_geometry_for(int G) const {
         for (const auto& r : tower_table) if (G > r.min_games) return r.geometry;
@@ -40,9 +46,10 @@ struct NetWeights {
     // cluster tower (k_tower_cl): batches of at most max_games boards run the 38 layers in one launch, boards_per_group
     // boards per 8-workgroup cluster (1, 2, 4: K split over 8 waves; 8: over 4 waves); tried in order, a batch no rule
     // takes (or whose grid would not be co-resident) runs per-layer kernels.  Measured (scripts/cluster_check.py), forward
-    // of 16 / 64 / 128 / 200 / 256 boards: 121 / 149 / 207 / 318 / 346 us against 250 / 253 / 317 / 564 / 426 before.  DIEE_TOWER_CL="max:boards,max:boards" overrides ("none" disables).
+    // of 16 / 64 / 128 / 200 / 256 boards: 121 / 149 / 207 / 318 / 346 us against 250 / 253 / 317 / 564 / 426 before.  option tower_cl = "max:boards,max:boards" overrides ("none" disables).
     struct ClusterRule { int max_games, boards_per_group; };
-    std::vector<ClusterRule> cluster_table = {{32, 1}, {64, 2}, {128, 4}, {256, 8}};
+    static std::vector<ClusterRule> default_cluster_table() { return {{32, 1}, {64, 2}, {128, 4}, {256, 8}}; }
+    std::vector<ClusterRule> cluster_table = default_cluster_table();      // option "tower_cl"
     DevBuf<uint32_t> cl_sync;       // [kClusterMaxGroups] counters, 128 B apart
     bool cluster_used = false;      // a cluster launch went out since nn_cluster_used() was asked last
     int full_chip_boards = 1024;    // one pass of the chip through the 4-board fused tower (256 CUs x 4 boards); batches above

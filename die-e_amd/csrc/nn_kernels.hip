@@ -2003,13 +2003,11 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 
 // cluster tower (small batches): returns false when the grid could not be resident at once (the caller then
 // runs the per-layer path)
-static bool g_cl_pack = true;
-void nn_refresh_env() { const char* v = getenv("DIEE_CL_PACK"); g_cl_pack = v == nullptr || atoi(v) != 0; }
 
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd,
-                            const GrowReq* grow, bool* grown) {
+                            const GrowReq* grow, bool* grown, bool pack) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds_tower = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
@@ -2025,12 +2023,11 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
         capacity = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? cus : 0;
     }
     const int groups = (G + GT - 1) / GT;
-    // Few clusters share few XCDs (DIEE_CL_PACK=0: one XCD per cluster, round 2's layout): up to 8 clusters on TWO XCDs, up to 16 on four
+    // Few clusters share few XCDs (option cl_pack = 0: one XCD per cluster, round 2's layout): up to 8 clusters on TWO XCDs, up to 16 on four
     // -- at most 4 clusters = 32 workgroups per XCD, one per CU --, so that every XCD that streams the 44.8 MB of weights through its L2
     // does it for up to four clusters (FETCH_SIZE per launch at 4 boards: 45 MB against 181 MB; at 16: 181 against 362) and the
     // workgroups dispatched to the cluster-free XCDs are the growth blocks.  Measured per search iteration: 105.8 vs 108.4 us at 4 boards,
     // 106.4 vs 111.3 at 8, 108.1 vs 110.6 at 16 (one XCD for 4 boards: 108.1; four XCDs for 8: 107.8; profiles/r03s_cl_pack_*).
-    const bool pack = g_cl_pack;                                                                    // (DIEE_CL_PACK, nn_refresh_env: once per search / API call)
     int nx = !pack ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;
     if (64 * ((groups + nx - 1) / nx) > capacity) nx = 8;  // (a device with fewer CUs than the packed grid dispatches: one XCD per cluster)
     const int grid = 64 * ((groups + nx - 1) / nx);
@@ -2059,19 +2056,19 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
                           const void* whead, const float* bhead, const void* wfc, const float* bfc, float* hv, float* logits,
-                          const GrowReq* grow, bool* grown) {
+                          const GrowReq* grow, bool* grown, bool pack) {
     const ClusterHeads hd{(const u32x4*)whead, bhead, (const u32x4*)wfc, bfc, hv, logits};
     if (grown) *grown = false;
     switch (boards_per_group) {
 #if DIEE_CL_SPLIT4_SMALL      // timing experiment (another summation order than the per-layer reference): K split over 4 waves, one per SIMD, at 1 / 2 boards per cluster
-        case 1: return tower_cl_launch<1, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
-        case 2: return tower_cl_launch<2, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 1: return tower_cl_launch<1, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
+        case 2: return tower_cl_launch<2, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
 #else
-        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
-        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
+        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
+        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
 #endif
-        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);
-        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown);     // K split over 4 waves (one per SIMD)
+        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
+        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }

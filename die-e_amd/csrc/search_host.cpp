@@ -76,17 +76,16 @@ void free_search(SearchBufs* s) { delete s; }
 // ---- pinned host memory for the delivered fragments ------------------------------------------------------------------
 // The arrays of a diee_fragments are page-locked so that the copies out of HBM are real asynchronous DMA (pageable
 // destinations are staged by the runtime and block the host).  Pinning costs ~0.3 ms per MB, so blocks are kept when
-// diee_free_fragments hands them back (up to DIEE_PINNED_POOL_MB, default 8192) and the next call takes them again.
+// diee_free_fragments hands them back (up to option pinned_pool_mb, default 8192 MiB) and the next call takes them again.
 namespace {
 struct PinnedPool {
     std::mutex m;
     std::multimap<size_t, void*> idle;                 // size -> block
     std::unordered_map<void*, size_t> out;             // blocks handed out
     size_t idle_bytes = 0;
-    size_t cap_bytes() {
-        static const size_t cap = [] { const char* v = getenv("DIEE_PINNED_POOL_MB"); return (size_t)(v && *v ? strtoull(v, nullptr, 10) : 8192ull) << 20; }();
-        return cap;
-    }
+    // process-wide: option pinned_pool_mb of any ctx (the environment's DIEE_PINNED_POOL_MB through it, read when a ctx is created)
+    size_t cap = (size_t)8192 << 20;
+    size_t cap_bytes() { std::lock_guard<std::mutex> lk(m); return cap; }
     void* acquire(size_t bytes) {
         bytes = (std::max<size_t>(bytes, 1) + 0xFFFFFull) & ~(size_t)0xFFFFFull;      // 1 MiB granules
         {
@@ -113,7 +112,7 @@ struct PinnedPool {
             auto it = out.find(p);
             if (it == out.end()) return false;
             sz = it->second; out.erase(it);
-            if (idle_bytes + sz <= cap_bytes()) { idle.emplace(sz, p); idle_bytes += sz; return true; }
+            if (idle_bytes + sz <= cap) { idle.emplace(sz, p); idle_bytes += sz; return true; }
         }
         (void)hipHostFree(p);
         return true;
@@ -122,6 +121,20 @@ struct PinnedPool {
 PinnedPool& pinned_pool() { static PinnedPool* pool = new PinnedPool(); return *pool; }   // (never destroyed: the HIP runtime may be gone first)
 }  // namespace
 bool pinned_release(void* p) { return pinned_pool().release(p); }
+void pinned_pool_set_cap_mb(size_t mb) {
+    PinnedPool& P = pinned_pool();
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        P.cap = mb << 20;
+        while (P.idle_bytes > P.cap && !P.idle.empty()) {       // a lower cap gives idle blocks back at once, largest first
+            auto it = std::prev(P.idle.end());
+            drop.push_back(it->second); P.idle_bytes -= it->first; P.idle.erase(it);
+        }
+    }
+    for (void* p : drop) (void)hipHostFree(p);
+}
+size_t pinned_pool_cap_mb() { return pinned_pool().cap_bytes() >> 20; }
 
 namespace {
 
@@ -169,15 +182,10 @@ namespace {
 
 constexpr uint32_t kLiveWords = 1 + 4 * kMaxSegments;        // DeliverSummary at its largest; live_host[kLiveWords] = the flag word
 
-uint32_t env_u32(const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
-    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
-}
-
 void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
     if (!e.search) e.search = new SearchBufs();
     SearchBufs& B = *e.search;
-    const uint32_t per_exp = env_u32("DIEE_NODES_PER_EXPANSION", 128);
+    const uint32_t per_exp = std::max<uint32_t>(e.opt.nodes_per_expansion, 1);
     const uint32_t want_cap = (iterations + 1) * per_exp + 64;
     if (slots > B.slot_cap || want_cap > B.node_cap) {
         const uint32_t sc = std::max(slots, B.slot_cap), nc = std::max(want_cap, B.node_cap);
@@ -211,7 +219,7 @@ Slots slots_view(Engine& e, SearchBufs& B) {
     const NetHeads H = nn_heads(e, (int)B.slot_cap);      // the network's output buffers, sized for every slot
     return Slots{B.roots.p, B.eval_states.p, B.game_id.p, B.round.p, B.seg.p, B.leaf.p, B.sel.p, B.sel_value.p, B.leaf_term.p,
                  nullptr, H.logits, H.hv, H.wv, B.noise.p, B.root_value0.p, B.iter_flags.p, B.counters.p, B.slot_cnt.p, e.flags_dev.p,
-                 B.leaf_meta.p, B.path.p, B.path_len.p, B.grow_k.p, B.grow_code.p, std::min<uint32_t>(env_u32("DIEE_PATH_CAP", kPathCap), kPathCap)};
+                 B.leaf_meta.p, B.path.p, B.path_len.p, B.grow_k.p, B.grow_code.p, std::min<uint32_t>(e.opt.path_cap, kPathCap)};
 }
 Segs segs_view(SearchBufs& B, uint32_t n_segs) {
     return Segs{B.seg_seed.p, B.seg_first_id.p, B.seg_game0.p, B.seg_slots.p, B.seg_slots.p + kMaxSegments, n_segs, B.iter_cap};
@@ -255,8 +263,8 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     // The network-independent half of every expansion (legal plays, child states: k_grow) runs on a second stream beside
     // the evaluation of the leaf: main stream  select -> [network] -> k_expand<true>,  side stream  -> k_grow ->.
     // Two events order them: k_grow(it) starts after the k_expand that selected its leaves, the k_expand that commits
-    // the children starts after k_grow(it).  DIEE_SPLIT_EXPAND=0: the one-kernel expansion of rounds 1-2.
-    static const bool split = env_u32("DIEE_SPLIT_EXPAND", 0) != 0;
+    // the children starts after k_grow(it).  Option split_expand (default 0: the growth rides inside k_expand / the cluster launch).
+    const bool split = e.opt.split_expand != 0;
     if (split && !B.side) {
         HIPCHK(hipStreamCreateWithFlags(&B.side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&B.ev_main, hipEventDisableTiming));
@@ -270,10 +278,10 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
         HIPCHK(hipEventRecord(B.ev_side, B.side));
     };
     auto join = [&] { if (split) HIPCHK(hipStreamWaitEvent(st, B.ev_side, 0)); };
-    // DIEE_FC_GROW=1 (default off: measured null on the whole batch, 93.3 / 93.6 vs 93.3 / 93.5 games/s same box; -1 % per iteration at 600 boards, 0 at 1024): above 256 boards the policy FC is a launch of its own behind the fused tower; the search hooks it
+    // option fc_grow = 1 (default off: measured null on the whole batch, 93.3 / 93.6 vs 93.3 / 93.5 games/s same box; -1 % per iteration at 600 boards, 0 at 1024): above 256 boards the policy FC is a launch of its own behind the fused tower; the search hooks it
     // and sends k_fc_grow instead -- the FC's tiles plus one block per slot that grows the tree (legal plays, child states) for
     // this very iteration: same stream, no event, the growth hides behind the FC.  `hooked` tells which k_expand to send.
-    static const bool fc_grow = env_u32("DIEE_FC_GROW", 0) != 0;
+    const bool fc_grow = e.opt.fc_grow != 0;
     struct HookCtx { const Tree* T; const Slots* S; const Segs* G; uint32_t n, it; bool grown; } hc{&T, &S, &G, n, 0u, false};
     const NetWeights::FcHook hook{[](void* ctx, hipStream_t hst, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc,
                                      const uint32_t* n_rows) {
@@ -282,13 +290,12 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
         else launch_policy_fc(hst, hp, wfc, bfc, logits, Gfc, n_rows);                 // (a second chunk of rows: the tree is grown already)
     }, &hc};
     struct HookScope { NetWeights* w; ~HookScope() { w->fc_hook = nullptr; } } scope{e.net};
-    // DIEE_CL_GROW (default on): below 129 boards the evaluation is ONE cluster-tower launch, latency-bound, with CUs to spare while
+    // option cl_grow (default on): below 129 boards the evaluation is ONE cluster-tower launch, latency-bound, with CUs to spare while
     // fewer than ~28 games live (the tail of a batch: 130 of its 364 move-steps): the launch takes the growth along on extra
     // workgroups (GrowReq) -- no second stream, no event --, and the k_expand behind it only has the priors, the backpropagation and
     // the next descent left (16.2 -> 9.4 us on the chain between two evaluations).
-    const bool cl_grow = env_u32("DIEE_CL_GROW", 1) != 0;        // (read per search: the tests switch it inside one process)
-    const ExpandVariant xv{env_u32("DIEE_EXPAND2", 1) != 0, env_u32("DIEE_EXPAND2C", 1) != 0};      // likewise, and handed down to every launch
-    nn_refresh_env();                                            // (DIEE_CL_PACK)
+    const bool cl_grow = e.opt.cl_grow != 0;
+    const ExpandVariant xv{e.opt.expand2 != 0, e.opt.expand2c != 0};      // handed down to every launch
     GrowReq greq{T, S, G, n, 0u};
     struct GrowScope { NetWeights* w; ~GrowScope() { w->grow_req = nullptr; w->grow_done = false; } } gscope{e.net};
     auto forward = [&](uint32_t it, const NnRows* rws) {
@@ -327,11 +334,9 @@ bool cluster_starved(Engine& e) {
     SearchBufs& B = *e.search;
     e.d2h(B.live_host + kLiveWords, e.flags_dev.p, 1);
     e.sync();
-    // tests: DIEE_TEST_STARVE_AT=k treats the k-th check of the process as a starved hand-over (the fallback path has
+    // tests: option test_starve_at = k treats the k-th check of this ctx as a starved hand-over (the fallback path has
     // no other way to be exercised on a box with one process per GPU)
-    static const int starve_at = getenv("DIEE_TEST_STARVE_AT") ? atoi(getenv("DIEE_TEST_STARVE_AT")) : -1;
-    static int checks = 0;
-    const bool forced = ++checks == starve_at;
+    const bool forced = e.opt.test_starve_at > 0 && ++e.starve_checks == e.opt.test_starve_at;
     if (!(B.live_host[kLiveWords] & 4u) && !forced) return false;
     nn_disable_cluster(e);                                            // clears the flag bit and re-arms the counters
     fprintf(stderr, "[diee] cluster tower: a workgroup hand-over starved (is another process using this GPU?); "
@@ -367,14 +372,18 @@ struct FragBufs {          // host arrays of one diee_fragments until they are h
         if (rows <= cap) return;
         PinnedPool& P = pinned_pool();
         const size_t nc = std::max(rows, cap + cap / 2);
-        int8_t* o = (int8_t*)P.acquire(nc); float* p = (float*)P.acquire(nc * 1352 * sizeof(float));
-        float* st = (float*)P.acquire(nc * 144 * sizeof(float)); uint32_t* g = (uint32_t*)P.acquire(nc * sizeof(uint32_t));
-        if (!o || !p || !st || !g) { P.release(o); P.release(p); P.release(st); P.release(g); throw std::bad_alloc(); }
+        // page-locked where the runtime grants it; a host that refuses to pin more (8 ranks x several GB each) gets pageable memory
+        // instead -- the copies into it are staged by the runtime and block the host thread, the records are the same
+        auto get = [&](size_t bytes) { void* q = P.acquire(bytes); return q ? q : malloc(std::max<size_t>(bytes, 1)); };
+        int8_t* o = (int8_t*)get(nc); float* p = (float*)get(nc * 1352 * sizeof(float));
+        float* st = (float*)get(nc * 144 * sizeof(float)); uint32_t* g = (uint32_t*)get(nc * sizeof(uint32_t));
+        if (!o || !p || !st || !g) { give(o); give(p); give(st); give(g); throw std::bad_alloc(); }
         if (n) { memcpy(o, outcome, n); memcpy(p, ps, n * 1352 * sizeof(float)); memcpy(st, state, n * 144 * sizeof(float)); memcpy(g, game, n * sizeof(uint32_t)); }
         drop();
         outcome = o; ps = p; state = st; game = g; cap = nc;
     }
-    void drop() { PinnedPool& P = pinned_pool(); P.release(outcome); P.release(ps); P.release(state); P.release(game); outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; }
+    static void give(void* q) { if (q && !pinned_pool().release(q)) free(q); }      // (a block of the pool, or the malloc fallback)
+    void drop() { give(outcome); give(ps); give(state); give(game); outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; }
     void release(diee_fragments* f) { f->n = (uint32_t)n; f->outcome = outcome; f->ps = ps; f->state = state; f->game = game; outcome = nullptr; ps = nullptr; state = nullptr; game = nullptr; cap = n = 0; }
     ~FragBufs() { drop(); }
 };
@@ -489,7 +498,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     std::vector<uint64_t> frag_total(n_batches, 0);
     for (auto& ev : B.dl_events) ev.ensure((size_t)2 * n_games);
     B.ev_copy_armed[0] = B.ev_copy_armed[1] = false;
-    const uint32_t stage_rows = std::max<uint32_t>(env_u32("DIEE_DELIVER_STAGE_ROWS", 16384), 1);
+    const uint32_t stage_rows = std::max<uint32_t>(opt.deliver_stage_rows, 1);
     double deliver_secs = 0.0;
     uint64_t deliver_bytes = 0;
     if (deliver) {
@@ -503,7 +512,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
         }
         // first guess: 128 records per game (a random-init game runs ~107 plies); grown when a batch outruns it
         for (uint32_t k = 0; k < n_batches; ++k)
-            fb[k].reserve(std::min<size_t>((size_t)bt[k].n_games * frag_cap, (size_t)bt[k].n_games * env_u32("DIEE_DELIVER_ROWS_PER_GAME", 128) + 1024));
+            fb[k].reserve(std::min<size_t>((size_t)bt[k].n_games * frag_cap, (size_t)bt[k].n_games * opt.deliver_rows_per_game + 1024));
     }
     struct CopyDrain { hipStream_t st; ~CopyDrain() { if (st) (void)hipStreamSynchronize(st); } } drain{deliver ? B.copy : nullptr};   // (no copy may outlive its pinned target)
     const DeliverOut stage{B.dl_ps.p, B.dl_planes.p, B.dl_outcome.p, B.dl_game.p};
@@ -550,7 +559,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     std::vector<uint32_t> steps_of(n_batches, 0);                       // move-steps each batch took part in
     std::vector<uint32_t> live_of(n_batches);
     for (uint32_t k = 0; k < n_batches; ++k) live_of[k] = bt[k].n_games;
-    const bool trace_steps = getenv("DIEE_TRACE_STEPS") != nullptr;      // development: batch size of every move-step
+    const bool trace_steps = opt.trace_steps != 0;                        // development: batch size of every move-step
     while (n_live > 0 && (max_steps == 0 || step < max_steps)) {       // alpha_parallel.rs:129
         if (trace_steps) fprintf(stderr, "[diee] move-step %u: %u games alive\n", step, n_live);
         for (uint32_t k = 0; k < n_batches; ++k) if (live_of[k]) steps_of[k] = step + 1;

@@ -43,7 +43,7 @@ typedef enum {
     DIEE_OK = 0,
     DIEE_ERR_ARG = 1,          /* bad argument                                            */
     DIEE_ERR_HIP = 2,          /* HIP runtime error / no device / a starved in-launch hand-over (two PROCESSES
-                                  sharing one GPU: set DIEE_TOWER_CL=none)          */
+                                  sharing one GPU: diee_set_option(ctx, "shared_gpu", "1"))          */
     DIEE_ERR_NO_WEIGHTS = 3,   /* diee_load_weights has not been called                   */
     DIEE_ERR_CAPACITY = 4,     /* tree arena / sequence buffer overflow (never silent)    */
     DIEE_ERR_UNSUPPORTED = 5
@@ -149,6 +149,33 @@ diee_status diee_create(int device, int game_id, diee_ctx** out);
 void        diee_destroy(diee_ctx*);
 const char* diee_last_error(const diee_ctx*);      /* valid until the next call on the ctx */
 const char* diee_version(void);
+
+/* the PCI address ("0000:c1:00.0") of the GPU this library's HIP runtime calls `device` -- a host whose own framework carries a second
+ * HIP runtime (PyTorch does) compares it with what that runtime reports for the ordinal it is about to use, once, before diee_create:
+ * both runtimes enumerate the same visible devices, and a mismatch would put the engine and the host's tensors on different GPUs.
+ * No ctx needed; initialises this library's runtime.  DIEE_ERR_HIP: no such device. */
+diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_t cap);
+
+/* ---- options of a ctx ---------------------------------------------------------------------
+ * What a host may legitimately have to tell the engine, per ctx, as key / value strings (values: non-negative decimal integers, or
+ * for the two tables "a:b,c:d" | "none" | "default").  The environment is NOT consulted by any call below: it is read once, inside
+ * diee_create, as a development override of the defaults (DIEE_<KEY IN CAPITALS>); a host sets what it needs through this call.
+ *   shared_gpu            0 | 1   another PROCESS computes on this GPU (several ranks per GPU): the kernels whose workgroups wait
+ *                                 for each other inside a launch (cluster tower <= 256 boards, pair tower 129 ... 512) are not used;
+ *                                 the caller's training step does the same with diee_train_set_bn_coop(0).  Default 0.
+ *   tower_pair            0 | 1   the pair tower alone
+ *   tower_cl              "max_boards:boards_per_cluster,..."   the cluster tower's table ("none": per-layer kernels below 257 boards)
+ *   tower_table           "min_boards:geometry,..."             the fused tower's table (development)
+ *   compact               0 | 1   above 256 live games evaluate only the slots whose leaf needs it (default 1; 0 = every row, like the reference)
+ *   spec_eval             0 | 1   speculative leaf evaluation in the free rows of the launches of a batch's tail (default 1; same results)
+ *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
+ *                                 with several ranks per host: what each may retain)
+ *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)
+ *   cl_pack, cl_grow, expand2, expand2c, split_expand, fc_grow, fused_heads, cluster_heads, cluster_init, trace_steps,
+ *   trace_dispatch, test_starve_at                                                  development / test switches
+ * Unknown key or malformed value: DIEE_ERR_ARG.  Not for a tic-tac-toe ctx (DIEE_ERR_UNSUPPORTED). */
+diee_status diee_set_option(diee_ctx*, const char* key, const char* value);
+diee_status diee_get_option(diee_ctx*, const char* key, char* value /*[cap]*/, size_t cap);
 
 /* ---- network weights ---------------------------------------------------------------------
  * Replaces ResNet::new / VarStore::load (src/alphazero/nnet.rs:57-118, alphazero.rs:81-100).

@@ -31,16 +31,20 @@ def test_chunked_staging_and_grown_host_arrays_deliver_the_same_records(eng, mon
     assert ref["stats"]["deliver_bytes"] == n * (1352 * 4 + 144 * 4 + 1 + 4)
     # 7-row staging chunks (every delivery takes many gather + copy rounds) and host arrays sized for 1 record per game
     # (they grow several times in mid-flight: the copy stream is drained, the rows so far move to a bigger block)
-    monkeypatch.setenv("DIEE_DELIVER_STAGE_ROWS", "7")
-    monkeypatch.setenv("DIEE_DELIVER_ROWS_PER_GAME", "1")
-    out = eng.self_play_parallel(48, cfg, 1.25, seed=5)
+    eng.set_options(deliver_stage_rows=7, deliver_rows_per_game=1)
+    try:
+        out = eng.self_play_parallel(48, cfg, 1.25, seed=5)
+    finally:
+        eng.set_options(deliver_stage_rows=16384, deliver_rows_per_game=128)
     assert same(out, ref)
-    monkeypatch.delenv("DIEE_DELIVER_STAGE_ROWS"); monkeypatch.delenv("DIEE_DELIVER_ROWS_PER_GAME")
     # the round limit flushes (Q18: a game flushed twice in one step) through the same path
     cfg2 = diee_amd.MctsConfig(iterations=4, c=2.0, round_limit=9, dir_alpha=0.3, dir_eps=0.25)
     a = eng.self_play_parallel(40, cfg2, 1.25, seed=8)
-    monkeypatch.setenv("DIEE_DELIVER_STAGE_ROWS", "5")
-    b = eng.self_play_parallel(40, cfg2, 1.25, seed=8)
+    eng.set_option("deliver_stage_rows", 5)
+    try:
+        b = eng.self_play_parallel(40, cfg2, 1.25, seed=8)
+    finally:
+        eng.set_option("deliver_stage_rows", 16384)
     assert same(a, b) and (a["outcome"] == 0).all() and 40 * 6 <= len(a["outcome"]) <= 40 * 9      # (a skipped turn leaves no record)
 
 
@@ -83,9 +87,11 @@ def test_growth_at_batch_scale(eng, monkeypatch):
     cfg = diee_amd.MctsConfig(iterations=3, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     ref = eng.self_play_parallel(512, cfg, 1.25, seed=77, copy=False)
     assert len(ref["outcome"]) == ref["stats"]["fragments"] > 512 * 60
-    monkeypatch.setenv("DIEE_DELIVER_ROWS_PER_GAME", "16")
-    monkeypatch.setenv("DIEE_DELIVER_STAGE_ROWS", "1000")
-    out = eng.self_play_parallel(512, cfg, 1.25, seed=77, copy=False)
+    eng.set_options(deliver_rows_per_game=16, deliver_stage_rows=1000)
+    try:
+        out = eng.self_play_parallel(512, cfg, 1.25, seed=77, copy=False)
+    finally:
+        eng.set_options(deliver_stage_rows=16384, deliver_rows_per_game=128)
     assert same(out, ref)
     # order of the records: by the move-step that removed the game, then by game (a game's records are contiguous and in play order)
     g = ref["game"]

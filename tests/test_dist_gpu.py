@@ -58,3 +58,29 @@ def test_bench_two_ranks_on_the_one_gpu_over_gloo():
     rc1, one, err1 = _run([sys.executable, "bench.py", "--gpus", "1"] + args[2:], dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert rc1 == 0 and one is not None, err1
     assert one["stats"]["fragments"] == line["fragments_per_rank"][0]
+
+
+def test_two_ranks_take_turns_on_the_one_gpu_with_the_full_kernel_set(tmp_path):
+    """what 8 GPUs will run, as far as one GPU can show it: TWO processes under torch.distributed.run, each after torch.cuda.set_device +
+    process-group set-up, each with the kernel set a GPU of its own gets -- the in-launch hand-overs of the cluster tower (<= 128 boards)
+    and the pair tower (129 ... 512) LEFT ON -- taking turns on the shared GPU through a lock file around every engine call
+    (bench.py --share-lock; without it bench.py tells the engines `shared_gpu` through diee_set_option, previous test).  300 games per
+    rank played to completion cross every dispatch band below 513 boards; no hand-over starves, and rank 0's records are the ones it
+    produces alone."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DIEE_")}          # a clean environment: options travel through the ABI
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DIEE_BENCH_BACKEND="gloo")
+    args = ["--gpus", "2", "--steps", "1", "--iterations", "4", "--no-cpu-baseline", "--games", "300", "--pipeline", "0", "--hbm-only-steps", "0",
+            "--share-lock", str(tmp_path / "gpu.lock")]
+    port = str(29700 + os.getpid() % 90)
+    rc, line, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, "bench.py"] + args, env)
+    assert rc == 0, err
+    assert line is not None, err
+    assert "starved" not in err and "falling back" not in err, err
+    assert line["n_gpus"] == 2 and line["stats"]["games"] == 2 * 300 and line["stats"]["illegal_decodes"] == 0
+    assert len(line["value_per_rank"]) == 2 and all(v > 0 for v in line["value_per_rank"])
+    one_env = {k: v for k, v in os.environ.items() if not k.startswith("DIEE_")}
+    one_env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rc1, one, err1 = _run([sys.executable, "bench.py", "--gpus", "1"] + args[2:-2], one_env)
+    assert rc1 == 0 and one is not None, err1
+    assert one["stats"]["fragments"] == line["fragments_per_rank"][0]                   # same games, same kernels, same records

@@ -47,12 +47,11 @@ def test_status_codes_instead_of_panics(oracle, monkeypatch):
     assert ei.value.status == diee_amd.ERR_ARG
     e.close()
     # a tree arena that is too small is reported, never silently truncated
-    monkeypatch.setenv("DIEE_NODES_PER_EXPANSION", "1")
-    e2 = diee_amd.Engine(0); e2.load_weights(diee_amd.random_weights(0))
+    e2 = diee_amd.Engine(0); e2.load_weights(diee_amd.random_weights(0)); e2.set_option("nodes_per_expansion", 1)
     with pytest.raises(diee_amd.DieeError) as ei:
         e2.alpha_mcts_parallel(roots, diee_amd.MctsConfig.default(64))
     assert ei.value.status == diee_amd.ERR_CAPACITY
-    monkeypatch.delenv("DIEE_NODES_PER_EXPANSION")
+    e2.set_option("nodes_per_expansion", 128)
     r = e2.alpha_mcts_parallel(roots, diee_amd.MctsConfig.default(8))      # the engine stays usable afterwards
     assert np.allclose(r["probs"].sum(1), 1.0, atol=1e-5)
     e2.close()

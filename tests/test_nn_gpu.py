@@ -421,16 +421,16 @@ def test_pair_tower_is_bit_identical_to_the_fused_geometries(oracle, monkeypatch
 
 
 def test_packed_clusters_change_no_bit(oracle, monkeypatch):
-    """up to 8 clusters share two XCDs, up to 16 share four (DIEE_CL_PACK, default on): a mapping of workgroups to board groups,
+    """up to 8 clusters share two XCDs, up to 16 share four (option cl_pack, default on): a mapping of workgroups to board groups,
     not another arithmetic -- every batch size of the packed range gives the bits of the one-XCD-per-cluster layout"""
     import diee_amd
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(31, 10)[:40]
     e = diee_amd.Engine(0); e.load_weights(blob)
     for G in (1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 24):
-        monkeypatch.setenv("DIEE_CL_PACK", "0")
+        e.set_option("cl_pack", 0)
         p0, v0 = e.forward_t(states[:G])
-        monkeypatch.setenv("DIEE_CL_PACK", "1")
+        e.set_option("cl_pack", 1)
         for rep in range(3):                                  # (and run after run)
             p, v = e.forward_t(states[:G])
             assert (p == p0).all() and (v == v0).all(), (G, rep)

@@ -235,8 +235,7 @@ def test_compacted_evaluation_changes_nothing_but_the_row_count(oracle, monkeypa
     gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
     res = []
     for compact in ("1", "0"):
-        monkeypatch.setenv("DIEE_COMPACT", compact)
-        e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+        e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0)); e.set_option("compact", compact)
         res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 4, gids, rds, ref_quirks=True))
         e.close()
     a, b = res
@@ -251,7 +250,7 @@ def test_compacted_evaluation_changes_nothing_but_the_row_count(oracle, monkeypa
 @pytest.mark.parametrize("cap", ["1", "2", "3"])
 def test_parent_walk_backpropagation_equals_the_recorded_path(oracle, monkeypatch, cap):
     """k_expand backpropagates over the root-to-leaf path its selection recorded (one lane per level); selections deeper
-    than the record fall back to walking the parent indices.  DIEE_PATH_CAP lowers the record so that ordinary searches
+    than the record fall back to walking the parent indices.  option path_cap lowers the record so that ordinary searches
     reach the fallback in the stale-slot re-backpropagation (Q14), the terminal-leaf backpropagation of the descent and the
     ordinary one: results and counters identical to the default"""
     import diee_amd
@@ -263,9 +262,8 @@ def test_parent_walk_backpropagation_equals_the_recorded_path(oracle, monkeypatc
     gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 7
     res = []
     for c in (None, cap):
-        if c is None: monkeypatch.delenv("DIEE_PATH_CAP", raising=False)
-        else: monkeypatch.setenv("DIEE_PATH_CAP", c)
         e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+        if c is not None: e.set_option("path_cap", c)
         res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 5, gids, rds, ref_quirks=True))
         e.close()
     a, b = res
@@ -278,7 +276,7 @@ def test_parent_walk_backpropagation_equals_the_recorded_path(oracle, monkeypatc
 @pytest.mark.parametrize("n", [5, 20, 24, 40, 80])
 def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypatch, n):
     """while the cluster tower's grid leaves CUs free (1 ... 24, 33 ... 48, 65 ... 96 boards) the launch grows the tree of
-    the leaf under evaluation on extra workgroups and k_expand<true> only commits the children; DIEE_CL_GROW=0 creates
+    the leaf under evaluation on extra workgroups and k_expand<true> only commits the children; option cl_grow = 0 creates
     them after the evaluation (k_expand<false>): same visit distributions, same counters -- bear-off roots keep terminal
     and drained leaves (nothing to grow) in the mix, iterations = 60 reach arenas that are well filled"""
     import diee_amd
@@ -291,7 +289,7 @@ def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypa
     e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
     res = []
     for grow in ("1", "0"):
-        monkeypatch.setenv("DIEE_CL_GROW", grow)
+        e.set_option("cl_grow", grow)
         res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 6, gids, rds, ref_quirks=True))
     e.close()
     a, b = res
@@ -305,7 +303,7 @@ def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypa
 @pytest.mark.parametrize("n,iters", [(20, 60), (40, 40), (300, 24), (1024, 8)])
 def test_one_wave_and_two_wave_tree_kernels_agree(oracle, monkeypatch, n, iters):
     """k_expand runs on two waves per slot by default -- a growth wave (k_expand<true, 1>) or, where the tower launch grew the
-    tree, a commit wave (<true, 2>) beside the main wave; DIEE_EXPAND2=0 / DIEE_EXPAND2C=0 bring the one-wave kernels back
+    tree, a commit wave (<true, 2>) beside the main wave; options expand2 = 0 / expand2c = 0 bring the one-wave kernels back
     (<false, 0> / <true, 0>).  All four combinations: the same visit distributions and counters, from the tail's cluster
     launches (20, 40 roots) through the compacted pair tower (300) to the full chip (1024)"""
     import diee_amd
@@ -319,7 +317,7 @@ def test_one_wave_and_two_wave_tree_kernels_agree(oracle, monkeypatch, n, iters)
     e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
     res = []
     for two, two_c in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("DIEE_EXPAND2", two); monkeypatch.setenv("DIEE_EXPAND2C", two_c)
+        e.set_options(expand2=two, expand2c=two_c)
         res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 7, gids, rds, ref_quirks=True))
     e.close()
     a = res[0]
