@@ -461,7 +461,7 @@ def main(argv=None, engine_factory=None):
             "conv_seconds", "conv_launches", "conv_flops", "tower_seconds", "tower_launches", "tower_flops",
             "full_seconds", "full_launches", "full_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
-            "fragments", "illegal_decodes", "deliver_seconds", "deliver_bytes"]
+            "fragments", "illegal_decodes", "deliver_seconds", "deliver_bytes", "tail_iterations", "tail_launches", "tail_spec_rows"]
     keys += [f"{n}.{b}" for n in ("band_seconds", "band_launches", "band_flops") for b in range(len(BAND_NAMES))]
     frags_per_rank = [int(tot.get("fragments", 0))]
     # every rank's own rate over the shared clock window (games it retired / its own time inside the K calls): a straggler shows here
@@ -599,7 +599,13 @@ def main(argv=None, engine_factory=None):
                       # links, the 32-byte state) against the arena the engine reserves per live game ((iterations + 1) * 128 + 64 nodes)
                       "tree_nodes_per_search": tot["children"] / max(tot["plies"], 1) + 1,
                       "tree_bytes_per_search": 56 * (tot["children"] / max(tot["plies"], 1) + 1),
-                      "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64)},
+                      "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64),
+                      # the tail of a batch (<= 16 live games: die-e_amd/csrc/search_types.h Tail): search iterations the looping tree kernel ran,
+                      # the network launches they needed (one per iteration without it) and the rows evaluated on speculation, per batch
+                      "tail": {"iterations_per_step": tot.get("tail_iterations", 0) / max(args.steps, 1) / world,
+                               "launches_per_step": tot.get("tail_launches", 0) / max(args.steps, 1) / world,
+                               "speculative_rows_per_step": tot.get("tail_spec_rows", 0) / max(args.steps, 1) / world,
+                               "launches_per_iteration": tot.get("tail_launches", 0) / max(tot.get("tail_iterations", 0), 1)}},
             "roofline": dominant, "roofline_other": other,
             "value_per_rank": rank_values,           # games/s of each rank by its own clock (value = all games / the slowest rank's window)
             "pci_bus_id_per_rank": rank_pci,         # libdiee.so's GPU per rank, checked against torch's before the engine was created (N > 1)

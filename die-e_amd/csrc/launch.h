@@ -43,7 +43,9 @@ constexpr int kClusterMaxGroups = 64;
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
                           const void* whead = nullptr, const float* bhead = nullptr, const void* wfc = nullptr, const float* bfc = nullptr,
-                          float* hv = nullptr, float* logits = nullptr, const GrowReq* grow = nullptr, bool* grown = nullptr, bool pack = true);
+                          float* hv = nullptr, float* logits = nullptr, const GrowReq* grow = nullptr, bool* grown = nullptr, bool pack = true,
+                          const uint32_t* n_rows_dev = nullptr, uint32_t* rows_log = nullptr);
+                          // n_rows_dev: the rows to evaluate are counted on the device (<= G; 0: the launch returns at once); rows_log: where to note them
                           // grow: also grow the tree on extra workgroups if the whole grid stays resident (*grown tells)
 // train_kernels.hip (token layout [M][256] bf16; `partial` = train_stripes(M) * 768 + 1280 floats of scratch)
 int train_stripes(int M);
@@ -92,6 +94,9 @@ void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
 // the policy FC over Gfc rows (n_rows non-null: a compacted batch) and launch_grow(it) in ONE launch
 void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc, const uint32_t* n_rows,
                     const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
+// the tail of a batch (search_types.h, Tail): launch number q of a move-step's search -- takes in the rows of tower launch q - 1, runs
+// iterations while every live game's selected leaf has its evaluation, plans the rows of tower launch q
+void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q);
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
 // rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
 // count also goes to rows_log[log_idx])

@@ -281,13 +281,17 @@ struct TwoScratch {
 // TWO == 2 (with PRE, the children exist already): wave 1 is the COMMIT wave -- softmax over the logits row, masked priors of the children --
 // while wave 0 evaluates the value head, backpropagates and descends; same meeting point, wave 1 hands the leaf's new header over in LDS and
 // wave 0 stores it (the descent may be reading that header: nobody else may change it under its feet).
-template <bool PRE, int TWO = 0>
-__global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
-                                                           uint32_t next_it, float c) {
+// The body of one (slot, iteration): k_expand runs it once per launch; k_tail (the tail of a batch, below) runs it in a loop with the
+// network row taken from its cache of earlier evaluations (TAIL: `nr` points at the slot's row, rows are counted where they are planned).
+struct NetRow { const float* logits; const float* hv; };
+template <bool PRE, int TWO>
+using ExpandScratchOf = typename std::conditional<(TWO != 0), TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type;
+template <bool PRE, int TWO = 0, bool TAIL = false>
+__device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
+                                            uint32_t next_it, float c, uint32_t slot, ExpandScratchOf<PRE, TWO>& sc_all, NetRow nr) {
     static_assert(PRE || !TWO, "two waves: the second one is the growth");
-    __shared__ typename std::conditional<(TWO != 0), TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type sc_all;
+    static_assert(!TAIL || (!PRE && !TWO), "the tail loop runs the one-wave body");
     auto& sc = [&]() -> auto& { if constexpr (TWO) return sc_all.s; else return sc_all; }();
-    const uint32_t slot = blockIdx.x;
     if (slot >= n) return;
     if constexpr (TWO == 1) {
         if (threadIdx.x >= 64) {
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     const unsigned long long evals0 = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
     const uint32_t node = lterm ? 0u : leaf;
     const uint32_t m0 = lterm ? 0u : m0q;
-    const ValueHeadIn vh = value_head_load(S.hv + (size_t)row * 72, S.wv, lane);
+    const ValueHeadIn vh = value_head_load(TAIL ? nr.hv : S.hv + (size_t)row * 72, S.wv, lane);
     float lg[22];
-    if (TWO != 2 || !main_wave) softmax_load(S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
+    if (TWO != 2 || !main_wave) softmax_load(TAIL ? nr.logits : S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
     else {
 #pragma unroll
         for (int q = 0; q < 22; ++q) lg[q] = 0.0f;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
     if (active && main_wave) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
     if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals0 + (seg_end - seg_first);
-    if (root || S.slot_row == nullptr || !lterm) cn[SC_NN_ROWS] += 1;
+    if (!TAIL && (root || S.slot_row == nullptr || !lterm)) cn[SC_NN_ROWS] += 1;
 
     if (!root) {
         if (lterm) {
@@ -612,6 +616,187 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
 #ifdef DIEE_EXPAND_STAMPS
     if (threadIdx.x == 0) atomicAdd(&g_expand_stamps[15], 1ull);
 #endif
+}
+
+template <bool PRE, int TWO = 0>
+__global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
+                                                           uint32_t next_it, float c) {
+    __shared__ ExpandScratchOf<PRE, TWO> sc_all;
+    expand_body<PRE, TWO>(T, S, G, n, it, P, next_it, c, blockIdx.x, sc_all, NetRow{nullptr, nullptr});
+}
+
+// ---- the tail of a batch: iterations in a loop, network rows from the ring (search_types.h, Tail) ---------------------------------
+constexpr int kTailSpin = 1 << 20;
+// LDS of k_tail: the one-wave expansion's scratch while iterations run; when a launch has to be planned the same bytes hold a scratch
+// copy of the game's tree statistics (five words per node) for the virtual descents, and the candidates they find
+struct TailStage {
+    float vis[kTailLdsNodes], val[kTailLdsNodes], pri[kTailLdsNodes];
+    uint32_t meta[kTailLdsNodes], fc[kTailLdsNodes];
+    uint32_t cand[64];
+};
+constexpr size_t kTailLds = sizeof(TailStage) > sizeof(ExpandScratch) ? sizeof(TailStage) : sizeof(ExpandScratch);
+
+// the games' workgroups meet: every one has published its selection of iteration `it` (flags, selection record) and says whether its
+// leaf has its evaluation; returns the number of workgroups that said no.  One word per meeting, never reused within a move-step.
+__device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, int lane, uint32_t* err, uint32_t& misses) {
+    if (n == 1) { misses = hit ? 0u : 1u; return true; }
+    __threadfence();                                        // this workgroup's stores before its arrival
+    uint32_t v = 0;
+    if (lane == 0) {
+        atomicAdd(word, hit ? 1u : 0x10001u);
+        int spins = 0;
+        for (;;) {
+            v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v & 0xffffu) >= n) break;
+            if (++spins > kTailSpin) { atomicOr(err, 4u); v = 0xffffffffu; break; }      // (reported like a starved cluster hand-over)
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the others' stores before this workgroup's loads
+    misses = v >> 16;
+    return v != 0xffffffffu;
+}
+
+// Virtual descents: the search's own selection rule (select_slot: q + c * sqrt(N) / (n + 1) * p, last of equal maxima) run ahead on a
+// scratch copy of the statistics.  An evaluation that is not known yet counts as 0 (a random-init net's values are small; the
+// pricing run found the parent's mean no better), a known one as its value, a finished game as +-1 for the root's player
+// (alpha_mcts.rs:157-163); the unexpanded nodes the descents end on, not evaluated yet, are the candidates.  Heuristic only: which
+// rows a launch carries beside the demanded ones never shows in a result.
+__device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uint32_t used, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
+                                                 TailStage& st, int lane, float c, uint32_t want, uint32_t max_steps, uint32_t demanded, int root_player) {
+    const uint32_t nl = used < kTailLdsNodes ? used : kTailLdsNodes;
+    for (uint32_t i = lane; i < nl; i += 64) {
+        st.vis[i] = T.visits[base + i]; st.val[i] = T.value[base + i]; st.pri[i] = T.prior[base + i];
+        st.meta[i] = T.meta[base + i]; st.fc[i] = T.first_child[base + i];
+    }
+    __syncthreads();
+    uint32_t ncand = 0, fruitless = 0;
+    for (uint32_t step = 0; step < max_steps && ncand < want && fruitless < 8; ++step) {
+        uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
+        for (;;) {
+            mt = node < nl ? st.meta[node] : T.meta[base + node];
+            const uint32_t k = meta_nch(mt);
+            if (k == 0) break;
+            const uint32_t fc = node < nl ? st.fc[node] : T.first_child[base + node];
+            const float sq = sqrtf(node < nl ? st.vis[node] : T.visits[base + node]);
+            Best b{0.0f, -1};
+            for (uint32_t j = lane; j < k; j += 64) {
+                const uint32_t ci = fc + j;
+                const float vis = ci < nl ? st.vis[ci] : T.visits[base + ci], val = ci < nl ? st.val[ci] : T.value[base + ci];
+                const float pr = ci < nl ? st.pri[ci] : T.prior[base + ci];
+                const float q = vis == 0.0f ? 0.0f : val / vis;
+                const float s = q + (c * (sq / (vis + 1.0f))) * pr;
+                if (s == s && (b.j < 0 || !(b.s > s))) { b.s = s; b.j = (int)j; }
+            }
+            b = wave_best(b);
+            node = fc + (uint32_t)(b.j >= 0 ? b.j : (int)k - 1);
+            ++depth;
+            if ((uint32_t)lane == depth) mine = node;
+            if (depth >= 63) break;
+        }
+        const BgState ls = load_state(&T.state[base + node]);
+        const uint32_t cr = crow[node];
+        const float cv = cval[node];
+        const int w = bg_winner_dev(ls);
+        float x = 0.0f;
+        bool fresh = false;
+        if (w != 0) x = w == root_player ? 1.0f : -1.0f;
+        else if (cr != 0) x = cv;
+        else if (!(mt & kDrained) && node != demanded) {
+            const bool dup = __ballot((uint32_t)lane < ncand && st.cand[lane] == node) != 0ull;
+            fresh = !dup;
+        }
+        if (fresh) { if (lane == 0) st.cand[ncand] = node; ++ncand; fruitless = 0; } else ++fruitless;
+        if ((uint32_t)lane <= depth && mine < nl) { st.vis[mine] += 1.0f; st.val[mine] += x; }
+        __syncthreads();
+    }
+    return ncand;
+}
+
+struct TailArgs { Tail L; uint32_t q; };
+__global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n, SearchParams P, float c, TailArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char tail_smem[];
+    if ((blockIdx.x & 7u) != 0u) return;                    // one game per workgroup, all of them on XCD 0 under round-robin dispatch
+    const uint32_t slot = blockIdx.x >> 3;                  // (placement is speed only: they meet through agent-scope atomics)
+    if (slot >= n) return;
+    const Tail& L = A.L;
+    const int lane = threadIdx.x;
+    if (L.state[1] != 0u) return;                           // the search is complete: launches the host sent ahead have nothing to do
+    uint32_t it = L.state[0];
+    const size_t base = (size_t)slot * T.node_cap;
+    uint32_t* crow = L.crow + (size_t)slot * T.node_cap;
+    float* cval = L.cval + (size_t)slot * T.node_cap;
+    // ---- take in the rows of tower launch q - 1: which node each evaluated, its value for the virtual descents (any summation
+    // order will do there: an expansion computes its value from the row itself, with the search's own value head) ----
+    if (A.q > 0) {
+        const uint32_t pq = A.q - 1, nr = L.n_rows[pq] < kTailRows ? L.n_rows[pq] : kTailRows;
+        if ((uint32_t)lane < nr) {
+            const uint32_t rn = L.rows_node[pq * kTailRows + lane];
+            if ((rn >> 24) == slot) {
+                const float* h = L.hv + (size_t)(pq * kTailRows + lane) * 72;
+                float dot = 0.0f;
+                for (int i = 0; i < 72; ++i) dot += h[i] * S.wv[i];
+                const uint32_t node = rn & 0xFFFFFFu;
+                cval[node] = tanhf(dot + S.wv[72]);
+                crow[node] = pq * kTailRows + (uint32_t)lane + 1u;
+            }
+        }
+        __syncthreads();
+    }
+    ExpandScratch& sc = *reinterpret_cast<ExpandScratch*>(tail_smem);
+    bool lterm = false, hit = false;
+    uint32_t leaf = 0, misses = 0;
+    for (;;) {
+        lterm = S.leaf_term[slot] != 0;
+        leaf = S.leaf[slot];
+        const uint32_t cr = lterm ? 0u : crow[leaf];
+        hit = lterm || cr != 0u;
+        if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {              // timed out: the host repeats the search launch by launch
+            if (lane == 0) { L.state[1] = 2u; L.host[1] = 2u; __threadfence_system(); }
+            return;
+        }
+        if (misses != 0u) break;
+        const uint32_t ring = lterm ? 0u : cr - 1u;
+        expand_body<false, 0, true>(T, S, G, n, it, P, it + 1 < L.iterations ? it + 1 : kNoNext, c, slot, sc,
+                                    NetRow{L.logits + (size_t)ring * 1352, L.hv + (size_t)ring * 72});
+        ++it;
+        __syncthreads();                                    // lane 0's selection record before the whole wave reads it
+        if (it >= L.iterations) break;
+    }
+    const bool done = it >= L.iterations;
+    if (!done) {
+        // ---- plan tower launch q: the leaves without an evaluation, and in the rows that are left what the search is likely to
+        // select next (every game an equal share) ----
+        const uint32_t room = kTailRows - (misses < kTailRows ? misses : kTailRows);
+        const uint32_t want = room / n + (slot < room % n ? 1u : 0u);
+        TailStage& stg = *reinterpret_cast<TailStage*>(tail_smem);
+        const BgState rs = load_state(&T.state[base]);
+        uint32_t ncand = 0;
+        if (want > 0 && L.rollout_steps > 0)
+            ncand = tail_rollout(T, base, T.used[slot], crow, cval, stg, lane, c, want < 63u ? want : 63u, L.rollout_steps, hit ? kNone : leaf, st_player(rs));
+        const uint32_t mine_rows = (hit ? 0u : 1u) + ncand;
+        uint32_t start = 0;
+        if (lane == 0 && mine_rows) start = atomicAdd(&L.n_rows[A.q], mine_rows);
+        start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+        if ((uint32_t)lane < mine_rows && start + (uint32_t)lane < kTailRows) {
+            const uint32_t node = (!hit && lane == 0) ? leaf : stg.cand[lane - (hit ? 0 : 1)];
+            const uint32_t r = A.q * kTailRows + start + (uint32_t)lane;
+            store_state(&L.rows_state[r], (!hit && lane == 0) ? load_state(&S.eval_states[slot]) : load_state(&T.state[base + node]));
+            L.rows_node[r] = (slot << 24) | node;
+        }
+        if (lane == 0) {
+            uint32_t* cnt = S.slot_cnt + slot * SC_COUNT;
+            cnt[SC_NN_ROWS] += mine_rows;                   // rows this game sends through the network (speculative ones included)
+            if (ncand) atomicAdd(&L.state[3], ncand);
+        }
+    }
+    if (slot == 0 && lane == 0) {
+        L.state[0] = it; L.state[1] = done ? 1u : 0u;
+        if (!done) L.state[2] += 1u;
+        L.host[0] = it; L.host[1] = done ? 1u : 0u; L.host[2] = A.q;
+        __threadfence_system();
+    }
 }
 
 // ---- the part of an expansion that does not wait for the network --------------------------------------------------------
@@ -1012,6 +1197,16 @@ void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const f
     const int gx = (Gfc + 31) / 32;
     const FcArgs fc{hp, wfc, bfc, logits, Gfc, n_rows, gx};
     hipLaunchKernelGGL(k_fc_grow, dim3((unsigned)(gx * 43) + n), dim3(64), 0, st, fc, T, S, G, n, it);
+}
+void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q) {
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
+        (void)hipFuncSetAttribute((const void*)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds);
+        attr_set[dev & 15] = true;
+    }
+    hipLaunchKernelGGL(k_tail, dim3(8 * n), dim3(64), kTailLds, st, T, S, G, n, P, c, TailArgs{L, q});
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

@@ -309,7 +309,7 @@ void nn_reset_cluster(Engine& e) {
 // would not be co-resident on this device: the caller runs the per-layer kernels.
 // hv / logits non-null: the launch runs the head convs and the policy FC too (rows of this chunk)
 static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, uint16_t* actX, uint16_t* actH, float* hv = nullptr,
-                          float* logits = nullptr) {
+                          float* logits = nullptr, const uint32_t* n_rows_dev = nullptr, uint32_t* rows_log = nullptr) {
     const void* winit = W.wconv[0].p; const float* binit = W.bconv[0].p;
     const void* whead = logits ? W.wconv[39].p : nullptr;
     for (const auto& r : W.cluster_table) {
@@ -326,7 +326,7 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
                 else HIPCHK(hipStreamWaitEvent(e.stream, bt->ev, 0));
                 bool took = false;                                  // (an earlier chunk of this evaluation may have grown the tree already: only ever set)
                 const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack);
+                                                     whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack, n_rows_dev, rows_log);
                 if (took) W.grow_done = true;
                 if (ok) HIPCHK(hipEventRecord(bt->ev, e.stream));
                 return ok;
@@ -335,7 +335,7 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
         {
             bool took = false;
             const bool ok = launch_tower_cluster(e.stream, e.device, r.boards_per_group, actX, actH, W.wtower.p, W.btower.p, G, W.cl_sync.p, e.flags_dev.p, states, winit, binit,
-                                                 whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack);
+                                                 whead, W.bconv[39].p, W.wfc.p, W.bfc.p, hv, logits, W.grow_done ? nullptr : W.grow_req, &took, W.cl_pack, n_rows_dev, rows_log);
             if (took) W.grow_done = true;
             return ok;
         }
@@ -490,6 +490,43 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     return false;
 }
 
+// The tail of a batch (search_types.h, Tail): ONE cluster-tower launch (init block, 38 layers, head convs, policy FC inside) over up to
+// G_upper states whose number k_tail wrote to *n_rows_dev on the device, outputs straight into the caller's ring rows.  The kernel is
+// the one every batch of at most 32 boards runs (k_tower_cl<1, 8>: the same bits per row whatever shares the launch).  false = this
+// ctx cannot (no such cluster rule, or the grid would not be co-resident): the caller searches launch by launch instead.
+bool nn_tail_available(Engine& e, int G_upper) {
+    if (!e.net || !e.net->loaded) return false;
+    const NetWeights& W = *e.net;
+    if (!W.cluster_init || !W.cluster_heads || W.invariant) return false;
+    for (const auto& r : W.cluster_table) if (G_upper <= r.max_games) return r.boards_per_group == 1;
+    return false;
+}
+bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band) {
+    NetWeights& W = *e.net;
+    nn_reserve(e, G_upper);
+    const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
+    const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t* rows_log = nullptr;
+    if (sample) {
+        W.rows_log.ensure(kRowsLog);
+        HIPCHK(hipMemsetAsync(W.rows_log.p + seq, 0, sizeof(uint32_t), e.stream));
+        rows_log = W.rows_log.p + seq;
+        ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, e.stream));
+    }
+    const struct GrowReq* saved = W.grow_req; W.grow_req = nullptr;      // (k_tail grows the tree itself)
+    const bool ok = cluster_tower(e, W, G_upper, states_dev, W.actX.p, W.actH.p, hv_out, logits_out, n_rows_dev, rows_log);
+    W.grow_req = saved;
+    if (ok) W.cluster_used = true;
+    if (sample) {
+        if (ok) {
+            HIPCHK(hipEventRecord(ev1, e.stream));
+            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 2, (int)seq, boards_band});      // flops per ROW; a launch without rows is dropped at the harvest
+        } else { W.free_events.push_back(ev0); W.free_events.push_back(ev1); }
+    }
+    return ok;
+}
+
 // the cluster tower ran since the last call (its hand-over flag is worth a look)
 bool nn_cluster_used(Engine& e) {
     if (!e.net) return false;
@@ -531,7 +568,8 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     for (auto& p : W.pending) {
         float ms = 0.f;
         if (p.rows_seq >= 0) p.flops *= (double)rows_log[(size_t)p.rows_seq];      // compacted batch: flops per row x rows evaluated
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        const bool empty = p.rows_seq >= 0 && rows_log[(size_t)p.rows_seq] == 0;   // (a tail launch sent ahead of a search that was complete already)
+        if (!empty && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 1 || p.kind == 3) {
                 W.tower_seconds += ms * 1e-3; W.tower_launches += p.launches; W.tower_flops += p.flops;
                 if (p.kind == 3) { W.full_seconds += ms * 1e-3; W.full_launches += p.launches; W.full_flops += p.flops; }

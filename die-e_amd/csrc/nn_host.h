@@ -108,6 +108,8 @@ void nn_reserve(Engine& e, int G);
 bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev, const NnRows* rows = nullptr);
 struct NetHeads { const float* logits; const float* hv; const float* wv; };
 NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserved
+bool nn_tail_available(Engine& e, int G_upper);
+bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band);
 bool nn_cluster_used(Engine& e);
 void nn_disable_cluster(Engine& e);
 void nn_reset_cluster(Engine& e);

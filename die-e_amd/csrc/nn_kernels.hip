@@ -524,7 +524,9 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
                                                           const float* __restrict__ binit,   // [256]
                                                           ClusterHeads hd,                   // whead non-null: head convs + policy FC in here
                                                           GrowReq gr, int tower_blocks,      // tower_blocks > 0: the blocks behind them grow the tree
-                                                          int nx) {                          // XCDs that host clusters (8; fewer: DIEE_CL_PACK, see the launcher)
+                                                          int nx,                            // XCDs that host clusters (8; fewer: option cl_pack, see the launcher)
+                                                          const uint32_t* __restrict__ n_rows_dev,   // non-null: the boards to evaluate are counted on the device
+                                                          uint32_t* __restrict__ rows_log) {         // (<= the host's M / 24; 0: nothing to do) and noted here
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32, RS = 528, CPR = 32, NT = 64 * NSPLIT;
     constexpr int KS = 144 / NSPLIT;                // k-steps per wave: (16 / NSPLIT) channel steps x 9 taps
     constexpr int PF = 18;                          // weight fragments in flight per wave
@@ -559,14 +561,23 @@ __global__ __launch_bounds__(64 * NSPLIT) void k_tower_cl(uint16_t* X,          
     }
     const int nslice = j & 7, grp = xcd + nx * (j >> 3);            // a whole cluster on one XCD (measured 5-8 % faster than
                                                                     // slice s of every group on XCD s, which would stream 1/8 of the weights per XCD)
-    if (grp >= n_groups) return;
-    const int row0 = grp * ROWS;
-    uint32_t* cnt = sync + grp * 32;
-
+    // (the first layer's weight fragments are requested before the row count is looked at: its round trip hides behind them)
     const u32x4* wp = wt + ((size_t)nslice * 144 + wave * KS) * 64 + lane;
     u32x4 bq[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) bq[i] = wp[i * 64];
+    if (n_rows_dev) {
+        // the tail of a batch (search_types.h, Tail): k_tail planned this launch's rows on the device; the clusters beyond them
+        // return at once -- a cluster takes part in a launch as a whole or not at all, so the tags and counters it leaves behind
+        // are those of its last complete launch
+        const int nr = (int)*n_rows_dev < M / 24 ? (int)*n_rows_dev : M / 24;
+        if (rows_log && blockIdx.x == 0 && tid == 0) *rows_log = (uint32_t)nr;
+        M = nr * 24; n_groups = (nr + GT - 1) / GT;
+    }
+    if (grp >= n_groups) return;
+    const int row0 = grp * ROWS;
+    uint32_t* cnt = sync + grp * 32;
+
 
     int base[9][MF];
 #pragma unroll
@@ -2007,7 +2018,7 @@ void nn_set_tower_dbg(unsigned long long* p) { g_tower_dbg = p; }
 template <int GT, int NSPLIT>
 static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H, const void* wt, const float* bias, int G,
                             uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit, const ClusterHeads& hd,
-                            const GrowReq* grow, bool* grown, bool pack) {
+                            const GrowReq* grow, bool* grown, bool pack, const uint32_t* n_rows_dev, uint32_t* rows_log) {
     constexpr int ROWS = GT * 24, MF = (ROWS + 31) / 32;
     constexpr int lds_a = ((ROWS + 1) * 528 + 16 * 35 + 15) / 16 * 16, lds_p = NSPLIT * MF * 32 * kClusterPartStride;
     constexpr int lds_tower = lds_a + lds_p > 160 * 1024 ? (lds_a > lds_p ? lds_a : lds_p) : lds_a + lds_p;
@@ -2028,7 +2039,7 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
     // does it for up to four clusters (FETCH_SIZE per launch at 4 boards: 45 MB against 181 MB; at 16: 181 against 362) and the
     // workgroups dispatched to the cluster-free XCDs are the growth blocks.  Measured per search iteration: 105.8 vs 108.4 us at 4 boards,
     // 106.4 vs 111.3 at 8, 108.1 vs 110.6 at 16 (one XCD for 4 boards: 108.1; four XCDs for 8: 107.8; profiles/r03s_cl_pack_*).
-    int nx = !pack ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;
+    int nx = (!pack || n_rows_dev) ? 8 : groups <= 8 ? 2 : groups <= 16 ? 4 : 8;      // (rows counted on the device: any number of the G clusters may run)
     if (64 * ((groups + nx - 1) / nx) > capacity) nx = 8;  // (a device with fewer CUs than the packed grid dispatches: one XCD per cluster)
     const int grid = 64 * ((groups + nx - 1) / nx);
     if (grid > capacity || groups > kClusterMaxGroups) {
@@ -2049,26 +2060,27 @@ static bool tower_cl_launch(hipStream_t st, int device, uint16_t* X, uint16_t* H
     }
     const GrowReq none{};
     hipLaunchKernelGGL((k_tower_cl<GT, NSPLIT>), dim3(grid + extra), dim3(64 * NSPLIT), (extra || ride) ? lds_max : lds_tower, st, X, H, (const u32x4*)wt, bias, G * 24, groups,
-                       sync, err, g_tower_dbg, (const BgState*)states, (const u32x4*)winit, binit, hd, (extra || ride) ? *grow : none, extra ? grid : 0, nx);
+                       sync, err, g_tower_dbg, (const BgState*)states, (const u32x4*)winit, binit, hd, (extra || ride) ? *grow : none, extra ? grid : 0, nx,
+                       n_rows_dev, rows_log);
     return true;
 }
 // whead != nullptr: the launch also runs the head convs and the policy FC (hv / logits are written; X holds no output then)
 bool launch_tower_cluster(hipStream_t st, int device, int boards_per_group, uint16_t* X, uint16_t* H, const void* wt, const float* bias,
                           int G, uint32_t* sync, uint32_t* err, const void* states, const void* winit, const float* binit,
                           const void* whead, const float* bhead, const void* wfc, const float* bfc, float* hv, float* logits,
-                          const GrowReq* grow, bool* grown, bool pack) {
+                          const GrowReq* grow, bool* grown, bool pack, const uint32_t* n_rows_dev, uint32_t* rows_log) {
     const ClusterHeads hd{(const u32x4*)whead, bhead, (const u32x4*)wfc, bfc, hv, logits};
     if (grown) *grown = false;
     switch (boards_per_group) {
 #if DIEE_CL_SPLIT4_SMALL      // timing experiment (another summation order than the per-layer reference): K split over 4 waves, one per SIMD, at 1 / 2 boards per cluster
-        case 1: return tower_cl_launch<1, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
-        case 2: return tower_cl_launch<2, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
+        case 1: return tower_cl_launch<1, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);
+        case 2: return tower_cl_launch<2, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);
 #else
-        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
-        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
+        case 1: return tower_cl_launch<1, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);
+        case 2: return tower_cl_launch<2, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);
 #endif
-        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);
-        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack);     // K split over 4 waves (one per SIMD)
+        case 4: return tower_cl_launch<4, 8>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);
+        case 8: return tower_cl_launch<8, 4>(st, device, X, H, wt, bias, G, sync, err, states, winit, binit, hd, grow, grown, pack, n_rows_dev, rows_log);     // K split over 4 waves (one per SIMD)
         default: return false;
     }
 }

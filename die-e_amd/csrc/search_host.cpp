@@ -38,6 +38,14 @@ struct SearchBufs {
     DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
+    // the tail of a batch (search_types.h, Tail)
+    DevBuf<uint32_t> tl_crow, tl_rows_node, tl_words;          // tl_words = n_rows[launches] ++ state[4] ++ bar[2 * launches + 8]
+    DevBuf<float> tl_cval, tl_logits, tl_hv;
+    DevBuf<BgState> tl_rows_state;
+    uint32_t* tl_host = nullptr;                               // pinned, [4]
+    uint32_t tl_launches = 0, tl_node_cap = 0;
+    uint32_t tl_prev_need = 0;                                 // tower launches the previous move-step's search needed (sizes the first chunk)
+    uint64_t tl_iterations = 0, tl_launched = 0, tl_with_rows = 0, tl_spec_rows = 0, tl_syncs = 0;      // this call's totals
     // batches ("segments") in flight
     DevBuf<unsigned long long> seg_seed;
     DevBuf<uint32_t> seg_first_id, seg_game0, seg_slots;      // seg_slots = first_slot[kMaxSegments] ++ end_slot[kMaxSegments]
@@ -66,6 +74,7 @@ struct SearchBufs {
         if (side) (void)hipStreamDestroy(side);
         if (ev_main) (void)hipEventDestroy(ev_main);
         if (ev_side) (void)hipEventDestroy(ev_side);
+        if (tl_host) (void)hipHostFree(tl_host);
         if (noise_host) (void)hipHostFree(noise_host);
         if (live_host) (void)hipHostFree(live_host);
     }
@@ -245,6 +254,67 @@ void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint3
         dirichlet_host(bt[k].seed, step, alpha, 1352, B.noise_host + ((size_t)buf * kMaxSegments + k) * 1352);
 }
 
+// ---- the tail of a batch (search_types.h, Tail) -------------------------------------------------------------------------------
+bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
+    return e.opt.spec_eval != 0 && !e.opt.split_expand && n >= 1 && n <= kTailMaxSlots && cfg.iterations >= 1 && nn_tail_available(e, (int)kTailRows);
+}
+
+Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg) {
+    const uint32_t launches = cfg.iterations + 1;
+    if (launches > B.tl_launches || B.node_cap > B.tl_node_cap) {
+        const uint32_t L = std::max(launches, B.tl_launches), nc = std::max(B.node_cap, B.tl_node_cap);
+        B.tl_crow.ensure((size_t)kTailMaxSlots * nc); B.tl_cval.ensure((size_t)kTailMaxSlots * nc);
+        B.tl_rows_state.ensure((size_t)L * kTailRows); B.tl_rows_node.ensure((size_t)L * kTailRows);
+        B.tl_logits.ensure((size_t)L * kTailRows * 1352); B.tl_hv.ensure((size_t)L * kTailRows * 72);
+        B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8);
+        B.tl_launches = L; B.tl_node_cap = nc;
+    }
+    if (!B.tl_host) { HIPCHK(hipHostMalloc((void**)&B.tl_host, sizeof(uint32_t) * 4)); memset(B.tl_host, 0, sizeof(uint32_t) * 4); }
+    uint32_t* w = B.tl_words.p;
+    return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + B.tl_launches, w + B.tl_launches + 4,
+                B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps};
+}
+
+// The iterations of one move-step's search for n <= kTailMaxSlots live games, behind the root expansion (k_expand has selected every
+// game's leaf for iteration 0): k_tail(0), then pairs of { tower launch q over the rows k_tail(q) planned, k_tail(q + 1) }.  Every pair
+// completes at least one iteration, `iterations` pairs complete the search -- and far fewer do when the free rows of the launches
+// carried the right nodes.  Launches sent ahead of a search that is complete return at once (~2 us each), so the pairs go out in
+// chunks: as many as the previous move-step needed, then a few at a time, the host looking at the done word in between.
+void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& G, const diee_mcts_cfg& cfg, const SearchParams& P) {
+    SearchBufs& B = *e.search;
+    const Tail L = tail_view(e, B, cfg);
+    hipStream_t st = e.stream;
+    // crow of the slots in use (the trees are rebuilt every move-step), the row counts, state words and meeting words
+    HIPCHK(hipMemsetAsync(L.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
+    HIPCHK(hipMemsetAsync(B.tl_words.p, 0, sizeof(uint32_t) * ((size_t)B.tl_launches + 4 + 2 * (size_t)L.launches + 8), st));
+    B.tl_host[1] = 0; B.tl_host[2] = 0xFFFFFFFFu;
+    launch_tail(st, T, S, G, n, P, cfg.c, L, 0);
+    uint32_t q = 0, sent = 0;
+    uint32_t chunk = B.tl_prev_need ? B.tl_prev_need + 2 : std::max<uint32_t>(8u, cfg.iterations / 6);
+    bool done = false;
+    while (!done && q < cfg.iterations) {
+        const uint32_t end = std::min<uint32_t>(cfg.iterations, q + std::max<uint32_t>(chunk, 1u));
+        for (; q < end; ++q, ++sent) {
+            if (!nn_forward_tail(e, L.rows_state + (size_t)q * kTailRows, (int)kTailRows, L.n_rows + q, L.hv + (size_t)q * kTailRows * 72,
+                                 L.logits + (size_t)q * kTailRows * 1352, (int)n))
+                throw EngineError(DIEE_ERR_HIP, "tail search: the cluster tower could not be launched");
+            launch_tail(st, T, S, G, n, P, cfg.c, L, q + 1);
+        }
+        HIPCHK(hipGetLastError());
+        e.sync();
+        ++B.tl_syncs;
+        done = B.tl_host[1] != 0;
+        chunk = 4;
+    }
+    uint32_t words[4] = {0, 0, 0, 0};
+    e.d2h(words, L.state, 4);
+    e.sync();
+    // (a meeting that timed out raised the starved bit: cluster_starved() repeats the search launch by launch)
+    if (!done && !(words[1] == 2u)) throw EngineError(DIEE_ERR_HIP, "tail search: the iterations did not complete");
+    B.tl_prev_need = words[2];
+    B.tl_iterations += cfg.iterations; B.tl_launched += sent; B.tl_with_rows += words[2]; B.tl_spec_rows += words[3];
+}
+
 // alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round / seg (segment table uploaded, the
 // Dirichlet samples of this move-step in pinned buffer `buf`).  Enqueues only: no host synchronisation.
 void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, int buf, uint32_t flags) {
@@ -315,6 +385,13 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
     join();
     launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, split || hc.grown, xv);
+    if (tail_possible(e, n, cfg)) {
+        S.slot_row = nullptr;
+        tail_run(e, n, T, S, G, cfg, P);
+        launch_reduce_counters(st, S, G);
+        HIPCHK(hipGetLastError());
+        return;
+    }
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
         grow(it);
         const bool compacted = forward(it, &rows);                   // alpha_mcts.rs:186
@@ -417,6 +494,7 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     sync();
     const int se = net->sample_every; net->sample_every = 0;
     draw_noise(B, 0, one, step, cfg->dir_alpha);
+    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0;
     mcts_run(*this, n, 1, *cfg, 0, flags);
     if (cluster_starved(*this)) {                                   // repeat on the per-layer kernels
         HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
@@ -433,6 +511,7 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     if (stats) {
         read_counters(*this, 0, stats);
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->tail_iterations = B.tl_iterations; stats->tail_launches = B.tl_with_rows; stats->tail_spec_rows = B.tl_spec_rows;
     }
     check_overflow();
 }
@@ -549,6 +628,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     };
 
     upload_segments(*this, bt);
+    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0;
     nn_reset_timing(*this);
     launch_init_games(stream, Gm, G, n_games);
     draw_noise(B, 0, bt, 0, cfg->dir_alpha);
@@ -604,6 +684,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
             stats[k].move_steps = steps_of[k]; stats[k].seconds = secs; stats[k].fragments = frag_total[k];
         }
         stats[0].deliver_seconds = deliver_secs; stats[0].deliver_bytes = deliver_bytes;
+        stats[0].tail_iterations = B.tl_iterations; stats[0].tail_launches = B.tl_with_rows; stats[0].tail_spec_rows = B.tl_spec_rows;
     } else {
         nn_harvest(*this, nullptr);
     }

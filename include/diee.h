@@ -129,6 +129,12 @@ typedef struct {
     double   band_seconds[9];
     uint64_t band_launches[9]; /* sampled evaluations                                                                              */
     double   band_flops[9];
+    /* the tail of a batch (<= 16 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
+     * they needed (one per iteration without it), and the rows those launches evaluated on speculation (all batches of the call,
+     * reported with batch 0) */
+    uint64_t tail_iterations;
+    uint64_t tail_launches;
+    uint64_t tail_spec_rows;
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine (page-locked: every move-step's

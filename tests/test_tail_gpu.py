@@ -1,0 +1,112 @@
+"""The tail of a batch (<= 16 live games; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
+launch for as long as every selected leaf's evaluation is at hand, and the launches in between carry speculative rows.  Nothing of
+that may show in a result: every case here holds the engine -- with the path on, with it off, and with the speculation alone off --
+to the CPU oracle's lockstep search BIT FOR BIT, and asserts that the path really ran (`tail_iterations`) and really saved launches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xD1EE0001
+KEYS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    yield e
+    e.close()
+
+
+def gpu_eval(eng, oracle):
+    def fn(states_u8):
+        return eng.forward_t(states_u8.view(oracle.BG_STATE).reshape(-1))
+    return oracle.make_eval(fn, 1352)
+
+
+def cfgs(oracle, iters, **kw):
+    import diee_amd
+    d = dict(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25); d.update(kw)
+    return oracle.MctsCfg(**d), diee_amd.MctsConfig(**d)
+
+
+def roots_of(oracle, n, pick):
+    walk = oracle.random_walk_states(123, 60)
+    if pick == "late":                                   # bear-off: terminal leaves, idle iterations, stale slots (Q14), drained leaves (Q15)
+        return walk[walk["off"].max(axis=1) >= 12][3:3 + n]
+    if pick == "mixed":
+        late = walk[walk["off"].max(axis=1) >= 11][:n // 2]
+        return np.concatenate([late, walk[300:300 + 5 * (n - len(late)):5]])
+    return walk[150:150 + 6 * n:6]
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+@pytest.mark.parametrize("n,iters,pick", [(1, 100, "mid"), (1, 100, "late"), (2, 100, "mixed"), (3, 64, "late"), (5, 100, "mixed"),
+                                          (8, 100, "mid"), (16, 100, "mixed"), (16, 48, "late"), (4, 400, "mixed")])
+def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
+    states = roots_of(oracle, n, pick)
+    assert len(states) == n
+    ocfg, gcfg = cfgs(oracle, iters)
+    gids = np.arange(40, 40 + n, dtype=np.uint32); rds = (np.arange(n, dtype=np.uint32) * 3) % 11
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 9, gids, rds, quirks)
+    res = {}
+    for name, opts in (("tail", dict(spec_eval=1, spec_rollout_steps=24)), ("demanded rows only", dict(spec_eval=1, spec_rollout_steps=0)),
+                       ("launch per iteration", dict(spec_eval=0, spec_rollout_steps=24))):
+        eng.set_options(**opts)
+        try:
+            res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 9, gids, rds, ref_quirks=bool(quirks))
+        finally:
+            eng.set_options(spec_eval=1, spec_rollout_steps=24)
+    os_ = ostats.as_dict()
+    for name, r in res.items():
+        assert r["probs"].tobytes() == probs.tobytes(), (name, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
+        assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all(), name
+        assert (r["n_children"] == np.array([len(x["children"]) for x in roots], dtype=np.uint32)).all(), name
+        for key in KEYS:
+            assert r["stats"][key] == os_[key], (name, key, r["stats"][key], os_[key])
+    t, d, p = (res[k]["stats"] for k in ("tail", "demanded rows only", "launch per iteration"))
+    assert t["tail_iterations"] == d["tail_iterations"] == iters and p["tail_iterations"] == 0
+    assert d["tail_spec_rows"] == 0 and d["tail_launches"] <= iters          # no speculation: a launch per iteration that evaluates anything, none for idle ones
+    assert t["tail_launches"] <= d["tail_launches"]
+    if pick != "late":
+        assert t["tail_spec_rows"] > 0 and t["tail_launches"] < 0.6 * iters, (t["tail_launches"], iters)   # the speculation pays
+    assert t["nn_rows"] >= t["tail_spec_rows"]
+
+
+def test_tail_self_play_whole_games_bit_exact(eng, oracle):
+    """whole games through the tail: 14 games at iterations = 24 played to completion -- every move-step of this batch runs the looping
+    kernel -- records, policy targets, outcomes and counters equal to the oracle's, and to the engine with the path off"""
+    ocfg, gcfg = cfgs(oracle, 24, round_limit=70)                                   # (a round limit some games hit: Q18 / Q19 too)
+    ref = oracle.self_play_parallel(1, 14, ocfg, 1.25, 31, gpu_eval(eng, oracle), None, ref_quirks=1, first_game_id=500)
+    out = eng.self_play_parallel(14, gcfg, 1.25, seed=31, ref_quirks=True, first_game_id=500)
+    eng.set_option("spec_eval", 0)
+    try:
+        plain = eng.self_play_parallel(14, gcfg, 1.25, seed=31, ref_quirks=True, first_game_id=500)
+    finally:
+        eng.set_option("spec_eval", 1)
+    for o in (out, plain):
+        assert o["ps"].tobytes() == ref["ps"].tobytes() and o["state"].tobytes() == ref["state"].tobytes()
+        assert (o["outcome"] == ref["outcome"]).all() and (o["game"] == ref["game"]).all()
+        for key in KEYS:
+            assert o["stats"][key] == ref["stats"][key], key
+    st = out["stats"]
+    assert st["tail_iterations"] == 24 * st["move_steps"] and plain["stats"]["tail_iterations"] == 0
+    assert st["tail_launches"] < 0.7 * st["tail_iterations"]
+    print(f"[tail] 14 games x iterations 24: {st['move_steps']} move-steps, {st['tail_iterations']} iterations on {st['tail_launches']} launches "
+          f"({st['tail_spec_rows']} speculative rows); {st['seconds']:.2f} s against {plain['stats']['seconds']:.2f} s launch by launch")
+
+
+def test_tail_with_batches_side_by_side(eng, oracle):
+    """diee_self_play_multi in the tail: three batches of a few games share the looping kernel's lockstep, each with its own
+    `node_selected` flags and slot-0 bookkeeping (Q14): per batch the oracle's lockstep restatement, bit for bit"""
+    ocfg, gcfg = cfgs(oracle, 16, round_limit=50)
+    batches = [(5, 0, 71), (4, 100, 72), (6, 200, 73)]
+    ref, _ = oracle.self_play_multi(1, batches, ocfg, 1.25, gpu_eval(eng, oracle), None, ref_quirks=1)
+    out = eng.self_play_multi(batches, gcfg, 1.25, ref_quirks=True)
+    for o, r in zip(out, ref):
+        assert o["ps"].tobytes() == r["ps"].tobytes() and o["state"].tobytes() == r["state"].tobytes() and (o["outcome"] == r["outcome"]).all()
+        for key in KEYS:
+            assert o["stats"][key] == r["stats"][key], key
+    assert out[0]["stats"]["tail_iterations"] > 0
