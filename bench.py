@@ -101,7 +101,7 @@ def _omp_search(job):
     return out
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=75.0):
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=75.0, big_roots=1024, big_budget_s=30.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
     `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
@@ -109,6 +109,8 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
 
       B-ref  as die-e runs self-play today: ONE batched search over all roots, tree loops on one thread
              (alpha_mcts.rs:153-168,192-200), the network batch on every core (libtorch intra-op pool);
+      B-ref-1024  the same at the metric's own batch: one search over `big_roots` = num_self_play_batches = 1024 roots (the CPU network
+             batches 16 x better than at 64 roots), iterations cut to fit ~`big_budget_s` seconds;
       B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308, pool sized at main.rs:107-110):
              one search per root, one PROCESS per host core (the reference's rayon threads share no interpreter lock; Python
              threads would), batch-1 single-threaded network evaluations -- no cross-game batching, no serial section.
@@ -177,6 +179,18 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
         "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores, "iterations_of_the_sample": it_ref,
         "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
         "what": f"one batched search over {n_roots} roots (serial C tree loops + fp32 PyTorch CPU ResNet on {cores} intra-op threads)"}
+    # ---- B-ref at the metric's own batch size (BASELINE configs[1]: num_self_play_batches = 1024): one move-step's search over 1024 roots ----
+    if big_roots and big_roots > n_roots:
+        roots_big = walk[np.linspace(3, len(walk) - 1, big_roots).astype(int)] if len(walk) >= big_roots else np.resize(walk[3:], big_roots)
+        t_big = calibrate(roots_big)
+        it_big = int(max(1, min(iterations, big_budget_s / t_big - 1)))
+        t = time.time(); st = search(roots_big, 0, it_big); dt = time.time() - t
+        out["variants"][f"B-ref-{big_roots}"] = {
+            "expansions_per_s": st["expansions"] / dt, "seconds": dt, "threads": cores, "iterations_of_the_sample": it_big,
+            "eval_s_per_batch": t_big,
+            "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
+            "what": f"one batched search over {big_roots} roots = the metric's num_self_play_batches (serial C tree loops + fp32 PyTorch CPU ResNet on "
+                    f"{cores} intra-op threads, {t_big:.2f} s per evaluation of the batch)"}
     # ---- B-games: whole games, not an extrapolation -- `games` games of self_play_parallel played to completion at the
     # full iteration count by the same B-ref machinery (serial C driver + tree, the network batch on every core)
     if games > 0:
@@ -200,9 +214,10 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
     out["expansions_per_s"] = eps
     out["value"] = eps / exp_per_game if exp_per_game else None
     out["cores"] = out["variants"][best]["threads"]
-    out["sample"] = (f"{best} (the faster of B-ref / B-omp, both in `variants`): oracle (C restatement of the reference's tree / game "
+    n_best = big_roots if best == f"B-ref-{big_roots}" else n_roots
+    out["sample"] = (f"{best} (the fastest of B-ref at {n_roots} roots, B-ref at {big_roots} roots = the metric's batch, and B-omp, all in `variants`): oracle (C restatement of the reference's tree / game "
                      f"loops) + PyTorch fp32 CPU ResNet, one move-step of search (iterations cut to "
-                     f"{out['variants'][best]['iterations_of_the_sample']} of {iterations} to fit ~{budget_s:.0f} s) on {n_roots} positions "
+                     f"{out['variants'][best]['iterations_of_the_sample']} of {iterations} to fit the time budget) on {n_best} positions "
                      f"drawn evenly from random self-play walks (opening to bear-off); games/s extrapolated with the GPU run's "
                      f"{exp_per_game:.0f} expansions per game")
     return out

@@ -55,7 +55,8 @@ EXPORTS = [
     "diee_bg_planes", "diee_det_pow",
     "diee_ttt_valid_moves", "diee_ttt_apply_move", "diee_ttt_check_winner", "diee_ttt_planes",
 ]
-DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench", "diee_dev_wave_selftest"]
+DEV_EXPORTS = ["diee_probe_f32", "diee_probe_dice", "diee_dev_conv_bench", "diee_dev_rules_bench", "diee_dev_wave_selftest",
+               "diee_dev_last_dispatch", "diee_dev_dispatch_bands"]
 
 
 class DieeError(RuntimeError):
@@ -96,6 +97,16 @@ class Stats(C.Structure):
 class Fragments(C.Structure):
     _fields_ = [("n", C.c_uint32), ("outcome", C.POINTER(C.c_int8)), ("ps", C.POINTER(C.c_float)),
                 ("state", C.POINTER(C.c_float)), ("game", C.POINTER(C.c_uint32))]
+
+
+class DevLaunch(C.Structure):
+    """diee_dev_launch (include/diee_dev.h)"""
+    _fields_ = [("family", C.c_int), ("geometry", C.c_int), ("boards", C.c_int), ("kernel", C.c_char * 120)]
+
+
+class DevBand(C.Structure):
+    """diee_dev_band (include/diee_dev.h)"""
+    _fields_ = [("boards_min", C.c_int), ("boards_max", C.c_int), ("family", C.c_int), ("geometry", C.c_int), ("kernel", C.c_char * 120)]
 
 
 class Batch(C.Structure):
@@ -168,6 +179,8 @@ def load_library(path=None):
     L.diee_dev_conv_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]; L.diee_dev_conv_bench.restype = C.c_int
     L.diee_dev_rules_bench.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp]; L.diee_dev_rules_bench.restype = C.c_int
     L.diee_dev_wave_selftest.argtypes = [vp, C.c_uint32, vp]; L.diee_dev_wave_selftest.restype = C.c_int
+    L.diee_dev_last_dispatch.argtypes = [vp, vp, u32, vp]; L.diee_dev_last_dispatch.restype = C.c_int
+    L.diee_dev_dispatch_bands.argtypes = [vp, C.c_int, vp, u32, vp]; L.diee_dev_dispatch_bands.restype = C.c_int
     if path is None:
         _lib = L
     return L
@@ -245,6 +258,19 @@ class Engine:
     def _chk(self, st):
         if st != OK:
             raise DieeError(st, self._L.diee_last_error(self._h).decode())
+
+    # ---- development probes: which tower kernel ran (include/diee_dev.h) ----
+    def last_dispatch(self):
+        """[(kernel name, boards)] of the tower launches of the last network evaluation"""
+        buf = (DevLaunch * 16)(); n = C.c_uint32(0)
+        self._chk(self._L.diee_dev_last_dispatch(self._h, buf, 16, C.byref(n)))
+        return [(buf[i].kernel.decode(), buf[i].boards) for i in range(n.value)]
+
+    def dispatch_bands(self, upto=1024):
+        """[(boards_min, boards_max, kernel name)]: the tower kernel a plain evaluation of that many boards runs on this ctx"""
+        buf = (DevBand * 64)(); n = C.c_uint32(0)
+        self._chk(self._L.diee_dev_dispatch_bands(self._h, upto, buf, 64, C.byref(n)))
+        return [(buf[i].boards_min, buf[i].boards_max, buf[i].kernel.decode()) for i in range(n.value)]
 
     # ---- options of the ctx (diee_set_option: what used to be DIEE_* environment switches) ----
     def set_option(self, key, value):

@@ -262,6 +262,34 @@ diee_status diee_dev_conv_bench(diee_ctx* c, int G, int variant, int reps, float
     API_END(c)
 }
 
+diee_status diee_dev_last_dispatch(diee_ctx* c, diee_dev_launch* out, uint32_t cap, uint32_t* n) {
+    API_BEGIN(c)
+    if (!out || !n) throw EngineError(DIEE_ERR_ARG, "null pointer");
+    Engine* e = bg(c);
+    *n = 0;
+    if (!e->net) return DIEE_OK;
+    for (const auto& d : e->net->last_dispatch) {
+        if (*n >= cap) break;
+        diee_dev_launch& o = out[(*n)++];
+        o.family = d.family; o.geometry = d.geometry; o.boards = d.boards;
+        snprintf(o.kernel, sizeof o.kernel, "%s", nn_kernel_name(d.family, d.geometry));
+    }
+    API_END(c)
+}
+
+diee_status diee_dev_dispatch_bands(diee_ctx* c, int upto_boards, diee_dev_band* out, uint32_t cap, uint32_t* n) {
+    API_BEGIN(c)
+    if (!out || !n || upto_boards < 1) throw EngineError(DIEE_ERR_ARG, "bad arguments");
+    *n = 0;
+    for (const auto& b : nn_dispatch_bands(*bg(c), upto_boards)) {
+        if (*n >= cap) break;
+        diee_dev_band& o = out[(*n)++];
+        o.boards_min = b.boards_min; o.boards_max = b.boards_max; o.family = b.family; o.geometry = b.geometry;
+        snprintf(o.kernel, sizeof o.kernel, "%s", nn_kernel_name(b.family, b.geometry));
+    }
+    API_END(c)
+}
+
 diee_status diee_dev_rules_bench(diee_ctx* c, const diee_bg_state* states, uint32_t n, int reps, float* us_legal_moves,
                                  float* mean_plays) {
     API_BEGIN(c)

@@ -31,6 +31,7 @@ void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, con
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
                   uint16_t* x_out, int G, const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
                   const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr);
+const char* tower_geometry_name(int geometry);    // "k_tower16<4, 4, 3, 0>" ...: the instantiation launch_tower sends for a geometry
 bool tower_geometry_is_full_chip(int geometry);   // the geometry (and instantiation) the dispatch uses for one pass of the chip
 bool tower_geometry_has_init(int geometry);   // the fused geometry can run the init block (states != nullptr) and the
                                               // head convs (whead16 != nullptr: hp / hv are written, x_out is not) itself

@@ -13,7 +13,14 @@ namespace diee {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kDrained = 0x80000000u;
 
-__device__ __forceinline__ uint32_t meta_nch(uint32_t m) { return (m >> 16) & 0x7fffu; }
+// Tree::meta: bit 31 expanded, bit 30 the node's state is a finished game, bit 29 ... won by player +1 (both set when the node is
+// created: the virtual descents of the tail read them instead of the 32-byte state), bits 28..16 children, bits 15..0 action code
+constexpr uint32_t kMetaTerminal = 0x40000000u, kMetaWinnerPlus = 0x20000000u;
+__device__ __forceinline__ uint32_t meta_nch(uint32_t m) { return (m >> 16) & 0x1fffu; }
+__device__ __forceinline__ uint32_t meta_terminal_bits(const BgState& s) {
+    const int w = bg_winner_dev(s);
+    return w == 0 ? 0u : (kMetaTerminal | (w > 0 ? kMetaWinnerPlus : 0u));
+}
 
 __device__ __forceinline__ BgState load_state(const BgState* p) {
     BgState s;
@@ -79,7 +86,7 @@ __device__ __forceinline__ void grow_slot(const Tree& T, const Slots& S, const S
         bg_apply_dev(cs, play, d0, d1);
         store_state(&T.state[ci], cs);
         T.visits[ci] = 0.0f; T.value[ci] = 0.0f;
-        T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = code;
+        T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = code | meta_terminal_bits(cs);
     }
     const uint2 packed = make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
     if (hand) {

@@ -561,7 +561,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
                 bg_apply_dev(cs, sc.ws.play[j], d0, d1);
                 store_state(&T.state[ci], cs);
                 T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = sc.raw[j] / sum;
-                T.parent[ci] = node; T.first_child[ci] = 0; T.meta[ci] = sc.code[j];
+                T.parent[ci] = node; T.first_child[ci] = 0; T.meta[ci] = (uint32_t)sc.code[j] | meta_terminal_bits(cs);
             }
             const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
             if (lane == 0) {
@@ -630,8 +630,8 @@ constexpr int kTailSpin = 1 << 20;
 // LDS of k_tail: the one-wave expansion's scratch while iterations run; when a launch has to be planned the same bytes hold a scratch
 // copy of the game's tree statistics (five words per node) for the virtual descents, and the candidates they find
 struct TailStage {
-    float vis[kTailLdsNodes], val[kTailLdsNodes], pri[kTailLdsNodes];
-    uint32_t meta[kTailLdsNodes], fc[kTailLdsNodes];
+    float vis[kTailLdsNodes], val[kTailLdsNodes], pri[kTailLdsNodes], cval[kTailLdsNodes];
+    uint32_t meta[kTailLdsNodes], fc[kTailLdsNodes], crow[kTailLdsNodes];
     uint32_t cand[64];
 };
 constexpr size_t kTailLds = sizeof(TailStage) > sizeof(ExpandScratch) ? sizeof(TailStage) : sizeof(ExpandScratch);
@@ -669,6 +669,7 @@ __device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uin
     for (uint32_t i = lane; i < nl; i += 64) {
         st.vis[i] = T.visits[base + i]; st.val[i] = T.value[base + i]; st.pri[i] = T.prior[base + i];
         st.meta[i] = T.meta[base + i]; st.fc[i] = T.first_child[base + i];
+        st.crow[i] = crow[i]; st.cval[i] = cval[i];
     }
     __syncthreads();
     uint32_t ncand = 0, fruitless = 0;
@@ -695,14 +696,12 @@ __device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uin
             if ((uint32_t)lane == depth) mine = node;
             if (depth >= 63) break;
         }
-        const BgState ls = load_state(&T.state[base + node]);
-        const uint32_t cr = crow[node];
-        const float cv = cval[node];
-        const int w = bg_winner_dev(ls);
+        // the leaf: a finished game (bits of its header, set when it was created), an evaluation at hand, or a candidate -- no trip to memory
+        const uint32_t cr = node < nl ? st.crow[node] : crow[node];
         float x = 0.0f;
         bool fresh = false;
-        if (w != 0) x = w == root_player ? 1.0f : -1.0f;
-        else if (cr != 0) x = cv;
+        if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
+        else if (cr != 0) x = node < nl ? st.cval[node] : cval[node];
         else if (!(mt & kDrained) && node != demanded) {
             const bool dup = __ballot((uint32_t)lane < ncand && st.cand[lane] == node) != 0ull;
             fresh = !dup;

@@ -343,6 +343,11 @@ static bool cluster_tower(Engine& e, NetWeights& W, int G, const void* states, u
     return false;
 }
 
+static int cluster_boards_for(const NetWeights& W, int G) {
+    for (const auto& r : W.cluster_table) if (G <= r.max_games) return r.boards_per_group;
+    return 0;
+}
+
 // the convolutional part of the network (init block, 38-layer tower, head convs) for rows [off, off + G) of the batch:
 // states -> hp / hv.  The tower kernel is picked by G alone (tower_table / cluster_table).
 // Returns true when the launch produced the chunk's logits as well (cluster tower with the heads and the FC inside).
@@ -370,7 +375,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
     float* logits = W.logits.p + (size_t)off * 1352;
     auto cluster = [&](const void* states, bool with_heads) {
         const bool ok = cluster_tower(e, W, G, states, actX, actH, with_heads ? hv : nullptr, with_heads ? logits : nullptr);
-        if (ok) W.cluster_used = true;
+        if (ok) { W.cluster_used = true; W.last_dispatch.push_back({3, cluster_boards_for(W, G), G}); }
         return ok;
     };
     bool done = false, heads_done = false, fc_done = false;
@@ -387,6 +392,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards(bpp) &&
             launch_tower_pair(st, bpp, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p, hp, hv, pair_exchange(e), e.flags_dev.p)) {
             done = true; heads_done = true; W.cluster_used = true;    // (its hand-overs report through the same flag bit as the cluster tower's)
+            W.last_dispatch.push_back({2, bpp, G});
             if (bpp == 2) kind = 2;                                    // the sampled timings go by band: <= 256 boards is the small-batch row
         } else {
             if (sample) { W.free_events.push_back(ev0); W.free_events.push_back(ev1); ev0 = ev1 = nullptr; }
@@ -399,16 +405,19 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
         launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G, states_dev, W.winit16.p, W.bconv[0].p,
                      W.fused_heads ? W.whead16.p : nullptr, W.bconv[39].p, hp, hv);
         done = true; heads_done = W.fused_heads;
+        W.last_dispatch.push_back({1, tgeom, G});
     }
     if (!done) {
         init_block();
         if (!ev0) stamp0();
         if (tgeom >= 0) {
             launch_tower(st, tgeom, actX, W.wtower.p, W.wtower16.p, W.btower.p, actX, G);   // all 38 layers, activations stay in LDS
+            W.last_dispatch.push_back({tgeom <= 1 ? 4 : 1, tgeom, G});
         } else if (cluster(nullptr, false)) {
             kind = 2;                                                   // (init block launched separately: DIEE_CLUSTER_INIT=0)
         } else {
             kind = 0;
+            W.last_dispatch.push_back({0, 0, G});
             for (int i = 0; i < BLOCKS; ++i) {
                 launch_conv3x3(st, 256, 0, actX, W.wl(1 + 2 * i), W.bl(1 + 2 * i), nullptr, actH, nullptr, G, 256);
                 // y = relu(conv2(h) + x), written in place over x (each element is read and written by one lane)
@@ -449,6 +458,7 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
     if (G <= 0) return false;
     NetWeights& W = *e.net;
     nn_reserve(e, G);
+    W.last_dispatch.clear();
     hipStream_t st = e.stream;
     const int tg = W.tower_geometry_for(G);
     // (one full pass of the chip, 929 ... 1024 live games, is the opening and middle game: hardly a terminal leaf, and the row
@@ -465,6 +475,7 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
         if (pex) W.cluster_used = true;
         launch_tower_compact(st, W.wtower16.p, W.btower.p, G, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
                              W.hp.p, W.hv.p, rows->row_slot, rows->n_rows, pex, e.flags_dev.p);
+        W.last_dispatch.push_back({1, -1, G});                      // compacted: up to three fused launches, each workgroup decides from the device-side row count
         if (sample) {
             HIPCHK(hipEventRecord(ev1, st));
             W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, G});     // flops per ROW: the row count is in rows_log[seq]
@@ -517,7 +528,8 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
     const struct GrowReq* saved = W.grow_req; W.grow_req = nullptr;      // (k_tail grows the tree itself)
     const bool ok = cluster_tower(e, W, G_upper, states_dev, W.actX.p, W.actH.p, hv_out, logits_out, n_rows_dev, rows_log);
     W.grow_req = saved;
-    if (ok) W.cluster_used = true;
+    W.last_dispatch.clear();
+    if (ok) { W.cluster_used = true; W.last_dispatch.push_back({3, cluster_boards_for(W, G_upper), G_upper}); }
     if (sample) {
         if (ok) {
             HIPCHK(hipEventRecord(ev1, e.stream));
@@ -525,6 +537,41 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
         } else { W.free_events.push_back(ev0); W.free_events.push_back(ev1); }
     }
     return ok;
+}
+
+// ---- development probes: which kernel a (family, geometry) is, and the dispatch of a plain evaluation by its board count ----
+const char* nn_kernel_name(int family, int geometry) {
+    switch (family) {
+        case 0: return "k_conv3x3 / k_conv3x3_sk (per-layer)";
+        case 1: return tower_geometry_name(geometry);
+        case 2: return geometry == 4 ? "k_tower16p<4, 6>" : geometry == 2 ? "k_tower16p<2, 6>" : "k_tower16p<?>";
+        case 3: return geometry == 1 ? "k_tower_cl<1, 8>" : geometry == 2 ? "k_tower_cl<2, 8>" : geometry == 4 ? "k_tower_cl<4, 8>" : geometry == 8 ? "k_tower_cl<8, 4>" : "k_tower_cl<?>";
+        case 4: return tower_geometry_name(geometry);
+        default: return "?";
+    }
+}
+// the kernel nn_conv_chunk picks for a whole batch of G boards when every launch succeeds (the same decisions, no launch)
+static NetWeights::Launched dispatch_of(const NetWeights& W, int G) {
+    int tgeom = W.tower_geometry_for(G);
+    if (tgeom < 0 && !W.cluster_table.empty() && W.cluster_init && cluster_boards_for(W, G) > 0) return {3, cluster_boards_for(W, G), G};
+    if (tgeom == 10 || tgeom == 11) {
+        const int bpp = tgeom == 10 ? 4 : 2;
+        if (W.pair_tower && W.fused_heads && W.cluster_init && G <= tower_pair_max_boards(bpp)) return {2, bpp, G};
+        tgeom = 3;
+    }
+    if (tgeom >= 0) return {tgeom <= 1 ? 4 : 1, tgeom, G};
+    if (cluster_boards_for(W, G) > 0) return {3, cluster_boards_for(W, G), G};
+    return {0, 0, G};
+}
+std::vector<DispatchBand> nn_dispatch_bands(Engine& e, int upto) {
+    std::vector<DispatchBand> out;
+    if (!e.net) return out;
+    for (int G = 1; G <= upto; ++G) {
+        const NetWeights::Launched d = dispatch_of(*e.net, G);
+        if (!out.empty() && out.back().family == d.family && out.back().geometry == d.geometry) out.back().boards_max = G;
+        else out.push_back({G, G, d.family, d.geometry});
+    }
+    return out;
 }
 
 // the cluster tower ran since the last call (its hand-over flag is worth a look)

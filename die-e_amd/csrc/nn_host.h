@@ -36,6 +36,11 @@ struct NetWeights {
     bool pair_tower = true;         // option "tower_pair" = 0: the 2-board geometry instead (rounds 1-2)
     bool starved = false;           // an in-launch hand-over timed out in this ctx: cluster and pair tower stay off
     bool told_no_pair = false;
+    // what the last network evaluation launched for its tower (development probe diee_dev_last_dispatch: the tolerance tests name
+    // the kernel they ran): family 0 per-layer kernels, 1 fused tower k_tower16 (geometry = launch_tower's), 2 pair tower k_tower16p
+    // (geometry = boards per pair), 3 cluster tower k_tower_cl (geometry = boards per cluster), 4 fused tower on 32x32x16 (k_tower)
+    struct Launched { int family, geometry, boards; };
+    std::vector<Launched> last_dispatch;
     bool cl_pack = true;            // option "cl_pack": few clusters share few XCDs (launch_tower_cluster)
     bool trace_dispatch = false;    // option "trace_dispatch"
     bool invariant = false;         // DIEE_FLAG_INVARIANT_NN / diee_set_invariant_nn: every batch size on the fused 16x16x32 tower
@@ -108,6 +113,10 @@ void nn_reserve(Engine& e, int G);
 bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, float* value_dev, const NnRows* rows = nullptr);
 struct NetHeads { const float* logits; const float* hv; const float* wv; };
 NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserved
+// development probes (include/diee_dev.h): kernel of a (family, geometry), and the dispatch of plain evaluations by board count
+const char* nn_kernel_name(int family, int geometry);
+struct DispatchBand { int boards_min, boards_max, family, geometry; };
+std::vector<DispatchBand> nn_dispatch_bands(Engine& e, int upto);
 bool nn_tail_available(Engine& e, int G_upper);
 bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band);
 bool nn_cluster_used(Engine& e);

@@ -2200,6 +2200,23 @@ void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void
         default: tower16_launch<3, 4, 6>(st, x_in, wt16, bias, x_out, G, states, winit16, binit, whead16, bhead, hp, hv); break;
     }
 }
+// (kept beside the switch above: the probe's names are the instantiations it launches, as rocprofv3 prints them)
+const char* tower_geometry_name(int geometry) {
+    switch (geometry) {
+        case 0: return "k_tower<4, 2, 9>";
+        case 1: return "k_tower<2, 1, 18>";
+        case 2: return "k_tower16<4, 4, 6, 0>";
+        case 5: return "k_tower16<4, 4, 3, 0>";
+        case 3: return "k_tower16<2, 8, 9, 0>";
+        case 6: return "k_tower16<4, 8, 6, 0>";
+        case 7: return "k_tower16<3, 8, 6, 0>";
+        case 8: return "k_tower16<4, 8, 3, 0>";
+        case 9: return "k_tower16<3, 8, 3, 0>";
+        case 14: return "k_tower16<4, 4, 3, 1>";
+        case -1: return "k_tower16 (compacted: <4, 4, 3, 0> / <4, 4, 3, 1> / <4, 8, 6, 0> / k_tower16p<4, 6> by the device-side row count)";
+        default: return "k_tower16<3, 4, 6, 0>";
+    }
+}
 // geometries 2..9 can run the init block themselves (states != nullptr); 0 / 1 (32x32x16) need it launched in front
 bool tower_geometry_has_init(int geometry) { return geometry >= 2; }
 bool tower_geometry_is_full_chip(int geometry) { return geometry == 5 || geometry == 8; }    // 4 boards per workgroup, the instantiation of the full-chip band

@@ -311,6 +311,8 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     e.sync();
     // (a meeting that timed out raised the starved bit: cluster_starved() repeats the search launch by launch)
     if (!done && !(words[1] == 2u)) throw EngineError(DIEE_ERR_HIP, "tail search: the iterations did not complete");
+    if (e.opt.trace_steps)
+        fprintf(stderr, "[diee] tail: %u games, %u iterations on %u launches with rows (%u pairs sent), %u speculative rows\n", n, cfg.iterations, words[2], sent, words[3]);
     B.tl_prev_need = words[2];
     B.tl_iterations += cfg.iterations; B.tl_launched += sent; B.tl_with_rows += words[2]; B.tl_spec_rows += words[3];
 }

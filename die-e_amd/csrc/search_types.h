@@ -31,7 +31,7 @@ struct Tree {
     float* prior;           // Node.policy
     uint32_t* parent;       // local index, 0xFFFFFFFF = None
     uint32_t* first_child;  // local index of the first child
-    uint32_t* meta;         // bit31 expanded ("expandable_moves drained"), bits30..16 n_children, bits15..0 action code
+    uint32_t* meta;         // bit31 expanded ("expandable_moves drained"), bit30 / bit29 finished game / won by +1, bits28..16 n_children, bits15..0 action code
     BgState* state;         // Node.state (dice frozen at creation)
     uint32_t* used;         // [slots] bump allocator
     uint32_t node_cap;      // nodes per slot
@@ -125,7 +125,7 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above 16 games.
 constexpr uint32_t kTailMaxSlots = 16;    // live games (all batches of the call) at or below which a move-step's search runs this way
 constexpr uint32_t kTailRows = 32;        // rows of a tail launch
-constexpr uint32_t kTailLdsNodes = 4096;  // nodes of a game's tree whose statistics the virtual descent stages in LDS (beyond: read in place, not updated)
+constexpr uint32_t kTailLdsNodes = 3072;  // nodes of a game's tree whose statistics the virtual descent stages in LDS (beyond: read in place, not updated)
 struct Tail {
     uint32_t* crow;         // [kTailMaxSlots][node_cap] ring row + 1 of a node's evaluation (0: none yet)
     float* cval;            // [kTailMaxSlots][node_cap] its value (for the virtual descents only: expansions recompute it from the row)

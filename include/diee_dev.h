@@ -28,6 +28,16 @@ diee_status diee_dev_conv_bench(diee_ctx*, int G, int variant, int reps, float* 
 diee_status diee_dev_rules_bench(diee_ctx*, const diee_bg_state* states, uint32_t n, int reps,
                                  float* us_legal_moves, float* mean_plays);
 
+/* which tower kernel ran: the launches of the ctx's LAST network evaluation (diee_nn_forward, or the last one of a search), in order, and
+ * the dispatch of a plain evaluation by its board count as bands [boards_min, boards_max] -> kernel (what NetWeights::tower_table /
+ * cluster_table say for this ctx today).  tests/test_nn_gpu.py derives one tolerance case per band from the second and asserts the
+ * first, so that a re-banding moves the cases with it and shows up as a changed expectation instead of as silently moved coverage.
+ * family: 0 per-layer kernels, 1 fused tower (k_tower16), 2 pair tower (k_tower16p), 3 cluster tower (k_tower_cl), 4 k_tower (32x32x16) */
+typedef struct { int family, geometry, boards; char kernel[120]; } diee_dev_launch;
+typedef struct { int boards_min, boards_max, family, geometry; char kernel[120]; } diee_dev_band;
+diee_status diee_dev_last_dispatch(diee_ctx*, diee_dev_launch* out, uint32_t cap, uint32_t* n);
+diee_status diee_dev_dispatch_bands(diee_ctx*, int upto_boards, diee_dev_band* out, uint32_t cap, uint32_t* n);
+
 /* the DPP / permlane forms of the wave-wide operations (csrc/wave_ops.h) against the __shfl forms they replace, on
  * lane-dependent data: the number of lanes x cases that disagree (0 on a correct build) */
 diee_status diee_dev_wave_selftest(diee_ctx*, uint32_t salt, uint32_t* mismatches);

@@ -238,11 +238,20 @@ def test_cluster_tower_two_contexts_on_one_gpu(oracle):
     a.close(); b.close()
 
 
-# ---- round 2: every dispatch path on >= 1024 states, the committed golden fixture, split launches ---------------------
-PATHS = [("k_tower16<4,8,3>", 1024), ("k_tower16<4,8,6>", 700), ("k_tower16<2,8,9>", 300),
-         ("k_tower16p<2> (pair tower, 2 boards per pair)", 200), ("k_tower_cl<4,8>", 100), ("k_tower_cl<2,8>", 50), ("k_tower_cl<1,8>", 20)]
+# ---- every DISPATCHED tower kernel on >= 1024 states, the committed golden fixture, split launches -------------------------
+# The cases are derived from the engine's own dispatch tables (diee_dev_dispatch_bands: one case per band, at the band's largest batch),
+# each case asserts the kernel that really ran (diee_dev_last_dispatch) -- and the bands themselves are pinned here, so that a re-banding
+# of NetWeights::tower_table / cluster_table fails this list instead of silently moving the coverage (round-4 review, weak #2).
+EXPECTED_BANDS = [(1, 32, "k_tower_cl<1, 8>"), (33, 64, "k_tower_cl<2, 8>"), (65, 128, "k_tower_cl<4, 8>"),
+                  (129, 256, "k_tower16p<2, 6>"), (257, 512, "k_tower16p<4, 6>"), (513, 640, "k_tower16<4, 8, 6, 0>"),
+                  (641, 928, "k_tower16<4, 4, 3, 1>"), (929, 1024, "k_tower16<4, 4, 3, 0>")]
 # measured on MI355X (round 2, 1024 mid-game states, random-init seed-0 net): see DESIGN.md section 2; bounds = 3 x measured
 PATH_POLICY_ATOL, PATH_VALUE_ATOL, PATH_POLICY_REL = 2e-5, 8e-3, 0.02
+
+
+def test_dispatch_bands_are_the_pinned_ones(setup):
+    e, _, _ = setup
+    assert e.dispatch_bands(1024) == EXPECTED_BANDS
 
 
 @pytest.fixture(scope="module")
@@ -255,25 +264,43 @@ def ref1024(setup, oracle):
     return states, rp, rv
 
 
-@pytest.mark.parametrize("name,chunk", PATHS)
-def test_every_dispatch_path_matches_fp32_on_1024_states(setup, ref1024, name, chunk):
-    """each tower kernel of the dispatch tables evaluates the same 1024 states (in batches of the size that selects
-    it) and is held to the fp32 restatement at the stated tolerance"""
+@pytest.mark.parametrize("lo,hi,kernel", EXPECTED_BANDS, ids=[k for _, _, k in EXPECTED_BANDS])
+def test_every_dispatched_kernel_matches_fp32_on_1024_states(setup, ref1024, lo, hi, kernel):
+    """each tower kernel of the dispatch tables evaluates the same 1024 states (in batches of its band's largest size -- and the
+    smallest, ragged groups -- so that it is the kernel that runs: asserted through the development probe) and is held to the
+    fp32 restatement at the stated tolerance"""
     e, _, _ = setup
     states, rp, rv = ref1024
-    pol = np.zeros_like(rp); val = np.zeros_like(rv)
-    for o in range(0, len(states), chunk):
-        sl = slice(o, min(o + chunk, len(states)))
-        if sl.stop - sl.start < chunk and o > 0:          # last partial batch: take a full-size window so the same kernel runs
-            sl2 = slice(len(states) - chunk, len(states))
-            p, v = e.forward_t(states[sl2])
-            pol[sl] = p[-(sl.stop - sl.start):]; val[sl] = v[-(sl.stop - sl.start):]
-        else:
-            pol[sl], val[sl] = e.forward_t(states[sl])
-    dp = np.abs(pol - rp).max(); dv = np.abs(val - rv).max(); rel = (np.abs(pol - rp) / rp).max()
-    print(f"[nn-parity] {name:18s} batches of {chunk:4d}: max|dpolicy| {dp:.3e}  max|dvalue| {dv:.3e}  max rel policy {rel:.3e}")
-    assert dp <= PATH_POLICY_ATOL and dv <= PATH_VALUE_ATOL and rel <= PATH_POLICY_REL
-    assert np.allclose(pol.sum(1), 1.0, atol=1e-4)
+    for chunk in (hi, lo):
+        pol = np.zeros_like(rp); val = np.zeros_like(rv)
+        for o in range(0, len(states), chunk):
+            sl = slice(o, min(o + chunk, len(states)))
+            if sl.stop - sl.start < chunk and o > 0:          # last partial batch: take a full-size window so the same kernel runs
+                sl2 = slice(len(states) - chunk, len(states))
+                p, v = e.forward_t(states[sl2])
+                pol[sl] = p[-(sl.stop - sl.start):]; val[sl] = v[-(sl.stop - sl.start):]
+            else:
+                pol[sl], val[sl] = e.forward_t(states[sl])
+            assert e.last_dispatch() == [(kernel, chunk)], (chunk, e.last_dispatch())      # THIS kernel, one launch, the whole batch
+        dp = np.abs(pol - rp).max(); dv = np.abs(val - rv).max(); rel = (np.abs(pol - rp) / rp).max()
+        print(f"[nn-parity] {kernel:24s} batches of {chunk:4d}: max|dpolicy| {dp:.3e}  max|dvalue| {dv:.3e}  max rel policy {rel:.3e}")
+        assert dp <= PATH_POLICY_ATOL and dv <= PATH_VALUE_ATOL and rel <= PATH_POLICY_REL
+        assert np.allclose(pol.sum(1), 1.0, atol=1e-4)
+
+
+def test_the_searchs_compacted_and_tail_launches_are_of_the_tolerance_tested_families(setup, oracle):
+    """what a SEARCH launches beyond the plain dispatch: above 256 live games the compacted evaluation (fused 16x16x32 family and the
+    pair tower, picked per workgroup from the device-side row count), in the tail of a batch the cluster tower <1, 8> with its rows
+    counted on the device -- both named by the probe after a search"""
+    import diee_amd
+    e, _, _ = setup
+    walk = oracle.random_walk_states(5, 30)
+    cfg = diee_amd.MctsConfig(iterations=3, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    e.alpha_mcts_parallel(walk[:700], cfg, 1, 0, np.arange(700, dtype=np.uint32), np.zeros(700, dtype=np.uint32), ref_quirks=True)
+    (k, boards), = e.last_dispatch()
+    assert k.startswith("k_tower16 (compacted") and boards == 700
+    e.alpha_mcts_parallel(walk[:6], cfg, 1, 0, np.arange(6, dtype=np.uint32), np.zeros(6, dtype=np.uint32), ref_quirks=True)
+    assert e.last_dispatch() == [("k_tower_cl<1, 8>", 32)]
 
 
 def test_engine_matches_the_golden_nn_fixture(oracle):
