@@ -1,15 +1,22 @@
-"""Builds die-e_amd/libdiee.so for gfx950 with hipcc (in-tree; the .so travels to the GPU box)."""
+"""Builds die-e_amd/libdiee.so for gfx950 with hipcc (in-tree; the .so travels to the GPU box).
+
+    python die-e_amd/build.py [--force]          the product library: fixed compile-time switches, dispatched kernels only
+    python die-e_amd/build.py --dev [--force]    die-e_amd/libdiee_dev.so with -DDIEE_DEV_BUILD: the superseded / experimental kernels and
+                                                 diee_dev_conv_bench; DIEE_EXTRA_FLAGS=-DDIEE_... then overrides a switch of csrc/nn_common.h
+                                                 (DIEE_OUT names another output); scripts/ load it through DIEE_LIB
+"""
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, os.environ.get("DIEE_OUT", "libdiee.so"))      # diagnostic builds: DIEE_OUT=libdiee_clock.so DIEE_EXTRA_FLAGS=-D...
+DEV = "--dev" in sys.argv or os.environ.get("DIEE_DEV") == "1"
+OUT = os.path.join(HERE, os.environ.get("DIEE_OUT", "libdiee_dev.so" if DEV else "libdiee.so"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-EXTRA = os.environ.get("DIEE_EXTRA_FLAGS", "").split()      # development (e.g. -DDIEE_TOWER_ABLATE=1)
+EXTRA = (["-DDIEE_DEV_BUILD"] if DEV else []) + os.environ.get("DIEE_EXTRA_FLAGS", "").split()      # development (e.g. -DDIEE_TOWER_ABLATE=1: --dev only)
 COMMON = EXTRA + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           f"--offload-arch={ARCH}"]
 

@@ -57,10 +57,12 @@ struct Options {
     int shared_gpu = 0;                     // another PROCESS uses this GPU: no kernel of this ctx waits for a co-resident workgroup
                                             // (cluster and pair tower off; the caller's training step: diee_train_set_bn_coop(0))
     // search
-    int cl_grow = 1, expand2 = 1, expand2c = 1, split_expand = 0, fc_grow = 0;
-    int spec_eval = 1;                      // the tail of a batch (<= 16 live games): iterations in one launch while the leaves' evaluations are at
+    int cl_grow = 1, expand2 = 1, expand2c = 1;
+    int spec_eval = 1;                      // the tail of a batch (<= spec_max_games live games): iterations in one launch while the leaves' evaluations are at
                                             // hand, speculative rows in the launches in between (search_types.h, Tail); 0: one launch per iteration
     uint32_t spec_rollout_steps = 24;       // virtual descents per game and launch that look for those rows (0: demanded rows only)
+    uint32_t spec_max_games = 64;           // live games up to which a move-step's search runs in tail mode (<= 64)
+    uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
     uint32_t path_cap = 64, nodes_per_expansion = 128;
     // output delivery
     uint32_t deliver_stage_rows = 16384, deliver_rows_per_game = 128;

@@ -22,7 +22,7 @@ void launch_probe_dice(hipStream_t st, uint64_t seed, const uint32_t* ctr, uint3
 // may take along: the cluster tower runs it on extra workgroups of its own launch while the chip has CUs to spare.
 struct GrowReq { Tree T; Slots S; Segs G; uint32_t n, it; };
 
-// nn_kernels.hip
+// nn_conv_kernels.hip / nn_cluster_kernels.hip / nn_fused_kernels.hip / nn_pair_kernels.hip (shared device code: nn_common.h)
 void nn_setup_kernels();
 void nn_set_conv_variant(int v);   // 0 = pick by batch size, 1..4 = fixed geometry (development)
 void launch_planes_bf16(hipStream_t st, const void* states, uint32_t n, uint16_t* out);
@@ -31,6 +31,7 @@ void launch_conv3x3(hipStream_t st, int c_in, int mode, const uint16_t* act, con
 void launch_tower(hipStream_t st, int geometry, const uint16_t* x_in, const void* wt, const void* wt16, const float* bias,
                   uint16_t* x_out, int G, const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
                   const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr);
+bool tower_geometry_supported(int geometry);       // compiled into this build (the product build holds 3, 5, 6, 14; -DDIEE_DEV_BUILD all)
 const char* tower_geometry_name(int geometry);    // "k_tower16<4, 4, 3, 0>" ...: the instantiation launch_tower sends for a geometry
 bool tower_geometry_is_full_chip(int geometry);   // the geometry (and instantiation) the dispatch uses for one pass of the chip
 bool tower_geometry_has_init(int geometry);   // the fused geometry can run the init block (states != nullptr) and the
@@ -85,16 +86,10 @@ void launch_softmax_value(hipStream_t st, const float* logits, const float* hv, 
 
 // mcts_kernels.hip
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n);
-void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks);
 struct ExpandVariant { bool two = true, two_c = true; };    // options expand2 / expand2c
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown = false, ExpandVariant v = ExpandVariant{});   // next_it: iteration to select for afterwards, kNoNextIteration = none;
                                                                          // pre_grown: launch_grow(it) created the children already
-// the network-independent half of expansion `it` (legal plays, child states): runs beside the network evaluation on another stream
-void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
-// the policy FC over Gfc rows (n_rows non-null: a compacted batch) and launch_grow(it) in ONE launch
-void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc, const uint32_t* n_rows,
-                    const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it);
 // the tail of a batch (search_types.h, Tail): launch number q of a move-step's search -- takes in the rows of tower launch q - 1, runs
 // iterations while every live game's selected leaf has its evaluation, plans the rows of tower launch q
 void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q);

@@ -225,15 +225,6 @@ __device__ __forceinline__ void store_counters(const Slots& S, uint32_t slot, co
     static_assert(SC_ILLEGAL == 6 && SC_NN_ROWS == 7, "word 6 stays in memory");
     p[4] = cn[4]; p[5] = cn[5]; p[7] = cn[7];
 }
-__global__ __launch_bounds__(64) void k_select(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, float c, uint32_t quirks) {
-    const uint32_t slot = blockIdx.x;
-    if (slot >= n) return;
-    uint32_t cn[SC_COUNT];
-    load_counters(S, slot, cn);
-    select_slot(T, S, G, slot, G.n == 1 ? 0u : S.seg[slot], (int)threadIdx.x, it, c, quirks, cn, nullptr);
-    if (threadIdx.x == 0) store_counters(S, slot, cn);
-}
-
 // ---- expansion + backpropagation ---------------------------------------------------------------
 // dev builds (-DDIEE_EXPAND_STAMPS): shader-clock sums per phase of k_expand over all waves, read by scripts/expand_phases.py
 #ifdef DIEE_EXPAND_STAMPS
@@ -716,8 +707,10 @@ __device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uin
 struct TailArgs { Tail L; uint32_t q; };
 __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n, SearchParams P, float c, TailArgs A) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
-    if ((blockIdx.x & 7u) != 0u) return;                    // one game per workgroup, all of them on XCD 0 under round-robin dispatch
-    const uint32_t slot = blockIdx.x >> 3;                  // (placement is speed only: they meet through agent-scope atomics)
+    // one game per workgroup; up to 32 games all on XCD 0 under round-robin dispatch (grid = 8 n, every eighth block works), more
+    // games spread over the chip (placement is speed only: the workgroups meet through agent-scope atomics)
+    uint32_t slot = blockIdx.x;
+    if (gridDim.x == 8u * n) { if ((blockIdx.x & 7u) != 0u) return; slot = blockIdx.x >> 3; }
     if (slot >= n) return;
     const Tail& L = A.L;
     const int lane = threadIdx.x;
@@ -729,16 +722,16 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     // ---- take in the rows of tower launch q - 1: which node each evaluated, its value for the virtual descents (any summation
     // order will do there: an expansion computes its value from the row itself, with the search's own value head) ----
     if (A.q > 0) {
-        const uint32_t pq = A.q - 1, nr = L.n_rows[pq] < kTailRows ? L.n_rows[pq] : kTailRows;
-        if ((uint32_t)lane < nr) {
-            const uint32_t rn = L.rows_node[pq * kTailRows + lane];
+        const uint32_t pq = A.q - 1, nr = L.n_rows[pq] < L.rows ? L.n_rows[pq] : L.rows;
+        for (uint32_t r = lane; r < nr; r += 64) {
+            const uint32_t rn = L.rows_node[pq * L.rows + r];
             if ((rn >> 24) == slot) {
-                const float* h = L.hv + (size_t)(pq * kTailRows + lane) * 72;
+                const float* h = L.hv + (size_t)(pq * L.rows + r) * 72;
                 float dot = 0.0f;
                 for (int i = 0; i < 72; ++i) dot += h[i] * S.wv[i];
                 const uint32_t node = rn & 0xFFFFFFu;
                 cval[node] = tanhf(dot + S.wv[72]);
-                crow[node] = pq * kTailRows + (uint32_t)lane + 1u;
+                crow[node] = pq * L.rows + r + 1u;
             }
         }
         __syncthreads();
@@ -767,7 +760,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     if (!done) {
         // ---- plan tower launch q: the leaves without an evaluation, and in the rows that are left what the search is likely to
         // select next (every game an equal share) ----
-        const uint32_t room = kTailRows - (misses < kTailRows ? misses : kTailRows);
+        const uint32_t room = L.rows - (misses < L.rows ? misses : L.rows);
         const uint32_t want = room / n + (slot < room % n ? 1u : 0u);
         TailStage& stg = *reinterpret_cast<TailStage*>(tail_smem);
         const BgState rs = load_state(&T.state[base]);
@@ -778,9 +771,9 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         uint32_t start = 0;
         if (lane == 0 && mine_rows) start = atomicAdd(&L.n_rows[A.q], mine_rows);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-        if ((uint32_t)lane < mine_rows && start + (uint32_t)lane < kTailRows) {
+        if ((uint32_t)lane < mine_rows && start + (uint32_t)lane < L.rows) {
             const uint32_t node = (!hit && lane == 0) ? leaf : stg.cand[lane - (hit ? 0 : 1)];
-            const uint32_t r = A.q * kTailRows + start + (uint32_t)lane;
+            const uint32_t r = A.q * L.rows + start + (uint32_t)lane;
             store_state(&L.rows_state[r], (!hit && lane == 0) ? load_state(&S.eval_states[slot]) : load_state(&T.state[base + node]));
             L.rows_node[r] = (slot << 24) | node;
         }
@@ -796,36 +789,6 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         L.host[0] = it; L.host[1] = done ? 1u : 0u; L.host[2] = A.q;
         __threadfence_system();
     }
-}
-
-// ---- the part of an expansion that does not wait for the network --------------------------------------------------------
-// alpha_expand_tensor (node.rs:157-174) creates one child per legal play: state (apply_move with frozen dice), parent, action
-// code -- none of which depends on the evaluation of the leaf; only the priors do.  k_grow does that part for the leaf the
-// selection just chose, on a second stream WHILE the network evaluates it (one wave per slot; the tower leaves room for these
-// waves on every CU): legal plays, codes, child states and headers at [used, used + k) of the slot's arena -- not linked to
-// the parent and `used` not advanced, so the tree is unchanged until k_expand<true> commits them with their priors.
-// Slots::grow_k = k (kNone: nothing to expand here, or no room), Slots::grow_code = the codes, four per lane.
-__global__ __launch_bounds__(64) void k_grow(Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
-    __shared__ WaveScratch ws;
-    grow_slot(T, S, G, n, it, blockIdx.x, ws);
-}
-// The policy FC of an evaluation and the growth of the tree for the SAME iteration in one launch (batches above 256 boards,
-// where the FC is a launch of its own behind the fused tower): blocks [0, fc_blocks) are policy_fc_tile's (gx x 43 tiles),
-// the rest grow one slot each.  The two halves share nothing -- the FC reads the head features and writes logits, the
-// growth reads the selection and writes unlinked children -- so the 8 us of legal plays and child states disappear behind
-// the FC's 15 us instead of sitting in k_expand on the chain between two evaluations, with no cross-stream event.
-struct FcArgs { const uint16_t* hp; const void* wfc; const float* bfc; float* logits; int G; const uint32_t* n_rows; int gx; };
-__global__ __launch_bounds__(64) void k_fc_grow(FcArgs fc, Tree T, Slots S, Segs G, uint32_t n, uint32_t it) {
-    __shared__ WaveScratch ws;
-    const int fc_blocks = fc.gx * 43;
-    if ((int)blockIdx.x < fc_blocks) {
-        const int g0 = ((int)blockIdx.x % fc.gx) * 32, nslice = (int)blockIdx.x / fc.gx;
-        int Gr = fc.G;
-        if (fc.n_rows) { Gr = (int)*fc.n_rows; if (g0 >= Gr) return; }
-        policy_fc_tile(fc.hp, (const fc_u32x4*)fc.wfc, fc.bfc, fc.logits, Gr, g0, nslice, threadIdx.x);
-        return;
-    }
-    grow_slot(T, S, G, n, it, blockIdx.x - (uint32_t)fc_blocks, ws);
 }
 
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
@@ -1175,9 +1138,6 @@ __global__ __launch_bounds__(256) void k_deliver_copy(Games Gm, Segs G, const De
 void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n) {
     hipLaunchKernelGGL(k_init_roots, dim3((n + 255) / 256), dim3(256), 0, st, T, S, n);
 }
-void launch_select(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, float c, uint32_t quirks) {
-    hipLaunchKernelGGL(k_select, dim3(n), dim3(64), 0, st, T, S, G, n, it, c, quirks);
-}
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown, ExpandVariant v) {
     // v.two = false (DIEE_EXPAND2=0): one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
@@ -1188,15 +1148,6 @@ void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
     else if (v.two) hipLaunchKernelGGL((k_expand<true, 1>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
     else hipLaunchKernelGGL((k_expand<false, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);
 }
-void launch_grow(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
-    hipLaunchKernelGGL(k_grow, dim3(n), dim3(64), 0, st, T, S, G, n, it);
-}
-void launch_fc_grow(hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc, const uint32_t* n_rows,
-                    const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it) {
-    const int gx = (Gfc + 31) / 32;
-    const FcArgs fc{hp, wfc, bfc, logits, Gfc, n_rows, gx};
-    hipLaunchKernelGGL(k_fc_grow, dim3((unsigned)(gx * 43) + n), dim3(64), 0, st, fc, T, S, G, n, it);
-}
 void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q) {
     static bool attr_set[16] = {};
     int dev = 0;
@@ -1205,7 +1156,7 @@ void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
         (void)hipFuncSetAttribute((const void*)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds);
         attr_set[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k_tail, dim3(8 * n), dim3(64), kTailLds, st, T, S, G, n, P, c, TailArgs{L, q});
+    hipLaunchKernelGGL(k_tail, dim3(n <= 32 ? 8 * n : n), dim3(64), kTailLds, st, T, S, G, n, P, c, TailArgs{L, q});
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

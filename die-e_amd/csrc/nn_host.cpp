@@ -176,7 +176,17 @@ void Engine::apply_options() {
     }
     W.pair_tower = pair;
     if (opt.tower_table == "default") W.tower_table = pair ? NetWeights::default_tower_table() : NetWeights::default_tower_table_no_pair();
-    else parse_table(opt.tower_table, W.tower_table);
+    else {
+        std::vector<NetWeights::TowerRule> t;
+        parse_table(opt.tower_table, t);
+        for (const auto& r : t)
+            if (r.geometry != 10 && r.geometry != 11 && !tower_geometry_supported(r.geometry)) {
+                opt.tower_table = "default";
+                throw EngineError(DIEE_ERR_ARG, "option tower_table: geometry " + std::to_string(r.geometry) + " is not in this build (product: 3, 5, 6, 14 and "
+                                  "10 / 11 = the pair tower; python die-e_amd/build.py --dev has the others)");
+            }
+        W.tower_table = t;
+    }
     if (!pair) for (auto& r : W.tower_table) if (r.geometry == 10 || r.geometry == 11) r.geometry = 3;      // (a table that names the pair tower)
     if (!handoffs) W.cluster_table.clear();
     else if (opt.tower_cl == "default") W.cluster_table = NetWeights::default_cluster_table();
@@ -439,8 +449,7 @@ static bool nn_conv_chunk(Engine& e, const void* states_all, int off, int G, boo
 
 static void fc_launch(Engine& e, const uint16_t* hp, float* logits, int G, const uint32_t* n_rows = nullptr) {
     NetWeights& W = *e.net;
-    if (W.fc_hook) W.fc_hook->fn(W.fc_hook->ctx, e.stream, hp, W.wfc.p, W.bfc.p, logits, G, n_rows);
-    else launch_policy_fc(e.stream, hp, W.wfc.p, W.bfc.p, logits, G, n_rows);
+    launch_policy_fc(e.stream, hp, W.wfc.p, W.bfc.p, logits, G, n_rows);
 }
 
 // forward_t on G device-resident states -> policy_dev [G][1352] (softmax), value_dev [G] (tanh).
@@ -509,7 +518,8 @@ bool nn_tail_available(Engine& e, int G_upper) {
     if (!e.net || !e.net->loaded) return false;
     const NetWeights& W = *e.net;
     if (!W.cluster_init || !W.cluster_heads || W.invariant) return false;
-    for (const auto& r : W.cluster_table) if (G_upper <= r.max_games) return r.boards_per_group == 1;
+    // (1, 2 and 4 boards per cluster split K over 8 waves: one arithmetic; 8 boards per cluster splits it over 4: another)
+    for (const auto& r : W.cluster_table) if (G_upper <= r.max_games) return r.boards_per_group == 1 || r.boards_per_group == 2 || r.boards_per_group == 4;
     return false;
 }
 bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band) {
@@ -647,6 +657,7 @@ void nn_reset_timing(Engine& e) {
     for (int b = 0; b < (int)DIEE_BANDS; ++b) { e.net->band_seconds[b] = 0; e.net->band_launches[b] = 0; e.net->band_flops[b] = 0; }
 }
 
+#ifdef DIEE_DEV_BUILD
 // development probe: average device time of the tower conv kernel (modes 0 and 1) at batch G
 void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward) {
     if (!e.net || !e.net->loaded) throw EngineError(DIEE_ERR_NO_WEIGHTS, "diee_load_weights has not been called");
@@ -723,6 +734,11 @@ void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, flo
     nn_set_conv_variant(0);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
 }
+#else
+void nn_conv_bench(Engine&, int, int, int, float*, float*, float*) {
+    throw EngineError(DIEE_ERR_UNSUPPORTED, "diee_dev_conv_bench needs the development build (python die-e_amd/build.py --dev; load it through DIEE_LIB)");
+}
+#endif
 
 void Engine::nn_forward_host(const diee_bg_state* states, uint32_t n, float* policy, float* value) {
     HIPCHK(hipSetDevice(device));

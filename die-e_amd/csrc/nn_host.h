@@ -61,11 +61,6 @@ struct NetWeights {
                                     // it run whole multiples in one launch and the remainder in a launch of its own (0: never split)
     bool fused_heads = true;        // the fused tower runs the head convs itself (its output tile never leaves the CU)
     bool cluster_init = true;       // the cluster tower runs the init block itself (every workgroup, for its cluster's boards)
-    // the search's hook on the policy FC: when set, the FC launch of an evaluation goes out through it (so that the search can
-    // fuse the network-independent half of its expansion into the same launch, k_fc_grow); an evaluation may launch the FC
-    // once, twice (rows in two chunks) or not at all (the cluster tower runs it itself)
-    struct FcHook { void (*fn)(void* ctx, hipStream_t st, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int G, const uint32_t* n_rows); void* ctx; };
-    const FcHook* fc_hook = nullptr;
     // the search's growth request for the evaluation about to be launched (launch.h GrowReq; null: none) and whether a launch took it
     const struct GrowReq* grow_req = nullptr;
     bool grow_done = false;

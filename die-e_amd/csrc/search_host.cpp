@@ -33,8 +33,6 @@ struct SearchBufs {
     DevBuf<uint8_t> leaf_term, path_len;
     DevBuf<uint32_t> path, leaf_meta, grow_k;
     DevBuf<uint16_t> grow_code;
-    hipStream_t side = nullptr;                                // k_grow runs here, beside the network on the engine's stream
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
     DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
@@ -71,9 +69,6 @@ struct SearchBufs {
     ~SearchBufs() {
         if (copy) (void)hipStreamDestroy(copy);
         for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
-        if (ev_main) (void)hipEventDestroy(ev_main);
-        if (ev_side) (void)hipEventDestroy(ev_side);
         if (tl_host) (void)hipHostFree(tl_host);
         if (noise_host) (void)hipHostFree(noise_host);
         if (live_host) (void)hipHostFree(live_host);
@@ -255,34 +250,40 @@ void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint3
 }
 
 // ---- the tail of a batch (search_types.h, Tail) -------------------------------------------------------------------------------
+// rows of a tail launch by live games: a launch of 32 / 64 / 128 boards costs ~95 / 125 / 172 us, and a search needs about
+// 91 / (1 + s) launches when every game gets s speculative rows per launch (s saturates near 8: the rows come from nodes that exist)
+uint32_t tail_rows_for(const Engine& e, uint32_t n) {
+    return n >= e.opt.spec_rows128_from ? 128u : n >= e.opt.spec_rows64_from ? 64u : 32u;
+}
 bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
-    return e.opt.spec_eval != 0 && !e.opt.split_expand && n >= 1 && n <= kTailMaxSlots && cfg.iterations >= 1 && nn_tail_available(e, (int)kTailRows);
+    return e.opt.spec_eval != 0 && n >= 1 && n <= std::min<uint32_t>(e.opt.spec_max_games, kTailMaxSlots) && cfg.iterations >= 1 &&
+           nn_tail_available(e, (int)tail_rows_for(e, n));
 }
 
-Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg) {
+Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     const uint32_t launches = cfg.iterations + 1;
     if (launches > B.tl_launches || B.node_cap > B.tl_node_cap) {
         const uint32_t L = std::max(launches, B.tl_launches), nc = std::max(B.node_cap, B.tl_node_cap);
         B.tl_crow.ensure((size_t)kTailMaxSlots * nc); B.tl_cval.ensure((size_t)kTailMaxSlots * nc);
-        B.tl_rows_state.ensure((size_t)L * kTailRows); B.tl_rows_node.ensure((size_t)L * kTailRows);
-        B.tl_logits.ensure((size_t)L * kTailRows * 1352); B.tl_hv.ensure((size_t)L * kTailRows * 72);
+        B.tl_rows_state.ensure((size_t)L * kTailRowsMax); B.tl_rows_node.ensure((size_t)L * kTailRowsMax);
+        B.tl_logits.ensure((size_t)L * kTailRowsMax * 1352); B.tl_hv.ensure((size_t)L * kTailRowsMax * 72);
         B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8);
         B.tl_launches = L; B.tl_node_cap = nc;
     }
     if (!B.tl_host) { HIPCHK(hipHostMalloc((void**)&B.tl_host, sizeof(uint32_t) * 4)); memset(B.tl_host, 0, sizeof(uint32_t) * 4); }
     uint32_t* w = B.tl_words.p;
     return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + B.tl_launches, w + B.tl_launches + 4,
-                B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps};
+                B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n)};
 }
 
-// The iterations of one move-step's search for n <= kTailMaxSlots live games, behind the root expansion (k_expand has selected every
+// The iterations of one move-step's search for n <= kTailMaxSlots (option spec_max_games) live games, behind the root expansion (k_expand has selected every
 // game's leaf for iteration 0): k_tail(0), then pairs of { tower launch q over the rows k_tail(q) planned, k_tail(q + 1) }.  Every pair
 // completes at least one iteration, `iterations` pairs complete the search -- and far fewer do when the free rows of the launches
 // carried the right nodes.  Launches sent ahead of a search that is complete return at once (~2 us each), so the pairs go out in
 // chunks: as many as the previous move-step needed, then a few at a time, the host looking at the done word in between.
 void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& G, const diee_mcts_cfg& cfg, const SearchParams& P) {
     SearchBufs& B = *e.search;
-    const Tail L = tail_view(e, B, cfg);
+    const Tail L = tail_view(e, B, cfg, n);
     hipStream_t st = e.stream;
     // crow of the slots in use (the trees are rebuilt every move-step), the row counts, state words and meeting words
     HIPCHK(hipMemsetAsync(L.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
@@ -295,8 +296,8 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     while (!done && q < cfg.iterations) {
         const uint32_t end = std::min<uint32_t>(cfg.iterations, q + std::max<uint32_t>(chunk, 1u));
         for (; q < end; ++q, ++sent) {
-            if (!nn_forward_tail(e, L.rows_state + (size_t)q * kTailRows, (int)kTailRows, L.n_rows + q, L.hv + (size_t)q * kTailRows * 72,
-                                 L.logits + (size_t)q * kTailRows * 1352, (int)n))
+            if (!nn_forward_tail(e, L.rows_state + (size_t)q * L.rows, (int)L.rows, L.n_rows + q, L.hv + (size_t)q * L.rows * 72,
+                                 L.logits + (size_t)q * L.rows * 1352, (int)n))
                 throw EngineError(DIEE_ERR_HIP, "tail search: the cluster tower could not be launched");
             launch_tail(st, T, S, G, n, P, cfg.c, L, q + 1);
         }
@@ -332,36 +333,6 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     HIPCHK(hipMemcpyAsync(B.noise.p, B.noise_host + (size_t)buf * kMaxSegments * 1352, sizeof(float) * 1352 * n_segs,
                           hipMemcpyHostToDevice, st));
     launch_init_roots(st, T, S, n);
-    // The network-independent half of every expansion (legal plays, child states: k_grow) runs on a second stream beside
-    // the evaluation of the leaf: main stream  select -> [network] -> k_expand<true>,  side stream  -> k_grow ->.
-    // Two events order them: k_grow(it) starts after the k_expand that selected its leaves, the k_expand that commits
-    // the children starts after k_grow(it).  Option split_expand (default 0: the growth rides inside k_expand / the cluster launch).
-    const bool split = e.opt.split_expand != 0;
-    if (split && !B.side) {
-        HIPCHK(hipStreamCreateWithFlags(&B.side, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&B.ev_main, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&B.ev_side, hipEventDisableTiming));
-    }
-    auto grow = [&](uint32_t it) {
-        if (!split) return;
-        HIPCHK(hipEventRecord(B.ev_main, st));
-        HIPCHK(hipStreamWaitEvent(B.side, B.ev_main, 0));
-        launch_grow(B.side, T, S, G, n, it);
-        HIPCHK(hipEventRecord(B.ev_side, B.side));
-    };
-    auto join = [&] { if (split) HIPCHK(hipStreamWaitEvent(st, B.ev_side, 0)); };
-    // option fc_grow = 1 (default off: measured null on the whole batch, 93.3 / 93.6 vs 93.3 / 93.5 games/s same box; -1 % per iteration at 600 boards, 0 at 1024): above 256 boards the policy FC is a launch of its own behind the fused tower; the search hooks it
-    // and sends k_fc_grow instead -- the FC's tiles plus one block per slot that grows the tree (legal plays, child states) for
-    // this very iteration: same stream, no event, the growth hides behind the FC.  `hooked` tells which k_expand to send.
-    const bool fc_grow = e.opt.fc_grow != 0;
-    struct HookCtx { const Tree* T; const Slots* S; const Segs* G; uint32_t n, it; bool grown; } hc{&T, &S, &G, n, 0u, false};
-    const NetWeights::FcHook hook{[](void* ctx, hipStream_t hst, const uint16_t* hp, const void* wfc, const float* bfc, float* logits, int Gfc,
-                                     const uint32_t* n_rows) {
-        HookCtx& h = *(HookCtx*)ctx;
-        if (!h.grown) { launch_fc_grow(hst, hp, wfc, bfc, logits, Gfc, n_rows, *h.T, *h.S, *h.G, h.n, h.it); h.grown = true; }
-        else launch_policy_fc(hst, hp, wfc, bfc, logits, Gfc, n_rows);                 // (a second chunk of rows: the tree is grown already)
-    }, &hc};
-    struct HookScope { NetWeights* w; ~HookScope() { w->fc_hook = nullptr; } } scope{e.net};
     // option cl_grow (default on): below 129 boards the evaluation is ONE cluster-tower launch, latency-bound, with CUs to spare while
     // fewer than ~28 games live (the tail of a batch: 130 of its 364 move-steps): the launch takes the growth along on extra
     // workgroups (GrowReq) -- no second stream, no event --, and the k_expand behind it only has the priors, the backpropagation and
@@ -370,23 +341,20 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     const ExpandVariant xv{e.opt.expand2 != 0, e.opt.expand2c != 0};      // handed down to every launch
     GrowReq greq{T, S, G, n, 0u};
     struct GrowScope { NetWeights* w; ~GrowScope() { w->grow_req = nullptr; w->grow_done = false; } } gscope{e.net};
+    bool grown = false;                                              // the tower launch of this evaluation took the growth along
     auto forward = [&](uint32_t it, const NnRows* rws) {
-        hc.it = it; hc.grown = false;
-        e.net->fc_hook = (fc_grow && !split) ? &hook : nullptr;
         greq.S = S; greq.it = it;
-        e.net->grow_req = (cl_grow && !split) ? &greq : nullptr;
+        e.net->grow_req = cl_grow ? &greq : nullptr;
         e.net->grow_done = false;
         const bool compacted = nn_forward(e, B.eval_states.p, (int)n, nullptr, nullptr, rws);
-        e.net->fc_hook = nullptr; e.net->grow_req = nullptr;
-        if (e.net->grow_done) hc.grown = true;
+        e.net->grow_req = nullptr;
+        grown = e.net->grow_done;
         return compacted;
     };
-    grow(kRootIteration);
     forward(kRootIteration, nullptr);                                // forward_policy, alpha_mcts.rs:104 (softmax / tanh in k_expand)
     const SearchParams P{cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
-    join();
-    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, split || hc.grown, xv);
+    launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, grown, xv);
     if (tail_possible(e, n, cfg)) {
         S.slot_row = nullptr;
         tail_run(e, n, T, S, G, cfg, P);
@@ -395,11 +363,9 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
         return;
     }
     for (uint32_t it = 0; it < cfg.iterations; ++it) {               // alpha_mcts.rs:149
-        grow(it);
         const bool compacted = forward(it, &rows);                   // alpha_mcts.rs:186
         S.slot_row = compacted ? B.slot_row.p : nullptr;
-        join();
-        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, split || hc.grown, xv);
+        launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, grown, xv);
     }
     launch_reduce_counters(st, S, G);
     HIPCHK(hipGetLastError());

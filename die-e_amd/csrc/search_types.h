@@ -112,9 +112,9 @@ struct DeliverSummary {     // indices into the per-step summary the host reads 
 struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; };    // staging, row-major
 
 // ---- the tail of a batch: speculative leaf evaluation (round 5) -----------------------------------------------------------------
-// At <= kTailMaxSlots live games a network evaluation costs the same ~95 us whether its launch carries 1 or 32 boards (one cluster-tower
-// launch, k_tower_cl<1, 8>), and a search iteration is one such launch + the tree kernel: 147 of a batch's 364 move-steps, a serial
-// chain of ~100 launches each.  But every leaf a search selects exists -- state, frozen dice -- from the moment its parent was
+// At <= 32 live games a network evaluation costs the same ~95 us whether its launch carries 1 or 32 boards (one cluster-tower
+// launch, k_tower_cl<1, 8>; 125 us up to 64, 172 us up to 128 boards), and a search iteration is one such launch + the tree kernel:
+// 147 of a batch's 364 move-steps are played with <= 32 live games, a serial chain of ~100 launches each.  But every leaf a search selects exists -- state, frozen dice -- from the moment its parent was
 // expanded, and below 129 boards a row's network output is a pure function of its state (the split-K cluster family is one
 // arithmetic, rows batch-independent: tests/test_nn_gpu.py).  So a launch's free rows carry unexpanded nodes the search is likely to
 // select next (found by a virtual descent of the same PUCT rule on a scratch copy of the tree's statistics: "UCB selection staged in
@@ -122,17 +122,19 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // earlier needs NO launch: k_tail (mcts_kernels.hip) runs the iterations of all live games in lockstep, one after the other inside
 // one launch, for as long as every selected leaf is in the ring, and plans the next launch's rows when one is not.  The search
 // itself -- selection, expansion, backpropagation, the quirks' coupling of the games of a batch -- is the same code on the same
-// numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above 16 games.
-constexpr uint32_t kTailMaxSlots = 16;    // live games (all batches of the call) at or below which a move-step's search runs this way
-constexpr uint32_t kTailRows = 32;        // rows of a tail launch
+// numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above 64 games.
+constexpr uint32_t kTailMaxSlots = 64;    // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
+constexpr uint32_t kTailRowsMax = 128;    // rows of a tail launch at most: 32 (k_tower_cl<1, 8>, ~95 us), 64 (<2, 8>, ~125 us) or 128 (<4, 8>, ~172 us) -- one
+                                          // arithmetic, so a row's bits do not depend on which of them evaluated it; the more games share a launch,
+                                          // the more rows it carries (Tail::rows, search_host.cpp tail_rows_for)
 constexpr uint32_t kTailLdsNodes = 3072;  // nodes of a game's tree whose statistics the virtual descent stages in LDS (beyond: read in place, not updated)
 struct Tail {
     uint32_t* crow;         // [kTailMaxSlots][node_cap] ring row + 1 of a node's evaluation (0: none yet)
     float* cval;            // [kTailMaxSlots][node_cap] its value (for the virtual descents only: expansions recompute it from the row)
-    BgState* rows_state;    // [launches][kTailRows] states the tower launch q evaluates
-    uint32_t* rows_node;    // [launches][kTailRows] slot << 24 | node
-    float* logits;          // [launches][kTailRows][1352] the ring
-    float* hv;              // [launches][kTailRows][72]
+    BgState* rows_state;    // [launches][rows] states the tower launch q evaluates
+    uint32_t* rows_node;    // [launches][rows] slot << 24 | node
+    float* logits;          // [launches][rows][1352] the ring
+    float* hv;              // [launches][rows][72]
     uint32_t* n_rows;       // [launches] rows of launch q (0: nothing to evaluate, the launch returns at once)
     uint32_t* state;        // [0] next iteration, [1] done, [2] launches that carried rows, [3] rows evaluated on speculation
     uint32_t* bar;          // [2 * launches + 8] one word per meeting of the games' workgroups (zeroed per move-step)
@@ -140,6 +142,7 @@ struct Tail {
     uint32_t launches;      // iterations + 1
     uint32_t iterations;
     uint32_t rollout_steps; // virtual descents per game and launch at most
+    uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128)
 };
 
 struct SearchParams {

@@ -177,7 +177,7 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
  *                                 with several ranks per host: what each may retain)
  *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)
- *   cl_pack, cl_grow, expand2, expand2c, split_expand, fc_grow, fused_heads, cluster_heads, cluster_init, trace_steps,
+ *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps, fused_heads, cluster_heads, cluster_init, trace_steps,
  *   trace_dispatch, test_starve_at                                                  development / test switches
  * Unknown key or malformed value: DIEE_ERR_ARG.  Not for a tic-tac-toe ctx (DIEE_ERR_UNSUPPORTED). */
 diee_status diee_set_option(diee_ctx*, const char* key, const char* value);

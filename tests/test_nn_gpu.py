@@ -87,76 +87,42 @@ def test_scaled_weights_stress_tolerance(setup, oracle):
     e2.close()
 
 
-def test_fused_tower_equals_layer_by_layer(oracle, monkeypatch):
-    """large batches run the 38-layer tower as one launch (activations stay in LDS); the arithmetic per
-    element is the same as the per-layer kernels of the same geometry class, so results are bit-identical"""
+def test_fused_geometries_are_one_arithmetic_and_match_the_per_layer_kernels(oracle):
+    """large batches run the 38-layer tower as one launch (activations stay in LDS).  The fused geometries of the product build --
+    4 boards x 4 waves (5; 14 = its second instantiation), 4 boards x 8 waves (6), 2 boards x 8 waves (3); the 4-board ones order their
+    16-row fragments by board region and do not issue the (tap, fragment) pairs that are all zero padding -- are ONE arithmetic per
+    output element: bit-identical to each other for full and ragged batches; the per-layer kernels (32x32x16 MFMA, another summation
+    order) agree with them to rounding, and both sit within the stated tolerance of fp32"""
     import diee_amd
     from oracle.nn_ref import parse, forward_t
     blob = diee_amd.random_weights(0)
-    states = oracle.random_walk_states(21, 12)[:700]
-    assert len(states) == 700
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:0")
-    e1 = diee_amd.Engine(0); e1.load_weights(blob)
-    p1, v1 = e1.forward_t(states)                 # fused (700 > 0)
-    p1s, v1s = e1.forward_t(states[:5])           # fused, ragged small batch (5 boards: padded workgroup)
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:1")
-    e3 = diee_amd.Engine(0); e3.load_weights(blob)
-    p3, v3 = e3.forward_t(states)                 # fused, 2 boards per workgroup (mid-size batches)
-    assert (p1 == p3).all() and (v1 == v3).all()
-    p3s, v3s = e3.forward_t(states[:5])
-    assert (p3s == p1s).all() and (v3s == v1s).all()
-    e3.close()
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "none")
-    e2 = diee_amd.Engine(0); e2.load_weights(blob)
-    p2, v2 = e2.forward_t(states)                 # per-layer kernels, 4 boards x 128 channels
-    assert (p1 == p2).all() and (v1 == v2).all()
-    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:40]))
-    assert np.abs(p1[:40] - rp).max() <= POLICY_ATOL and np.abs(v1[:40] - rv).max() <= VALUE_ATOL
-    assert np.abs(p1s - rp[:5]).max() <= POLICY_ATOL and np.abs(v1s - rv[:5]).max() <= VALUE_ATOL
-    e1.close(); e2.close()
-
-
-def test_border_aware_fragments_are_bit_identical(oracle, monkeypatch):
-    """the 4-board fused tower orders its 16-row fragments by board region (left / right column, top / bottom edge,
-    interior) and does not issue the (tap, fragment) pairs that are all zero padding: same bits as the dense order"""
-    import diee_amd
-    blob = diee_amd.random_weights(0)
-    states = oracle.random_walk_states(33, 12)[:1001]           # ragged: last workgroup has one board
+    states = oracle.random_walk_states(33, 12)[:1001]           # ragged: the last workgroup has one board
     assert len(states) == 1001
-    out = []
-    for geom in (8, 6, 5, 14, 9):                               # 4 boards (8 waves PF 3 / 6; round 4's product: 4 waves, k loop unrolled, both instantiations) vs 3 boards dense
-        monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
-        e = diee_amd.Engine(0); e.load_weights(blob)
-        out.append(e.forward_t(states)); out.append(e.forward_t(states[:7]))
+    out = {}
+    for geom in (5, 14, 6, 3):
+        e = diee_amd.Engine(0); e.load_weights(blob); e.set_option("tower_table", f"0:{geom}")
+        out[geom] = (e.forward_t(states), e.forward_t(states[:7]), e.forward_t(states[:301]))
+        assert e.last_dispatch()[0][0] == {5: "k_tower16<4, 4, 3, 0>", 14: "k_tower16<4, 4, 3, 1>", 6: "k_tower16<4, 8, 6, 0>", 3: "k_tower16<2, 8, 9, 0>"}[geom]
+        # row independence within the geometry
+        p2, v2 = e.forward_t(states[:301][::-1].copy())
+        assert (p2[::-1] == out[geom][2][0]).all() and (v2[::-1] == out[geom][2][1]).all()
         e.close()
-    for k in range(2, len(out), 2):
-        assert (out[k][0] == out[0][0]).all() and (out[k][1] == out[0][1]).all()
-        assert (out[k + 1][0] == out[1][0]).all() and (out[k + 1][1] == out[1][1]).all()
-    assert (out[1][0] == out[0][0][:7]).all()
-
-
-@pytest.mark.parametrize("geom", [3, 4, 5, 6, 7, 8])
-def test_fused_tower_16x16x32_geometries(oracle, monkeypatch, geom):
-    """the fused tower on v_mfma_f32_16x16x32_bf16 (2 / 3 / 4 boards per workgroup, 4 or 8 waves): same network, different
-    MFMA shape, so equal to the 32x32x16 kernels up to fp32 summation order, and within the stated tolerance of fp32"""
-    import diee_amd
-    from oracle.nn_ref import parse, forward_t
-    blob = diee_amd.random_weights(0)
-    states = oracle.random_walk_states(33, 4)[:301]          # ragged: not a multiple of 2, 3 or 4 boards
-    monkeypatch.setenv("DIEE_TOWER_TABLE", f"0:{geom}")
-    e = diee_amd.Engine(0); e.load_weights(blob)
-    p, v = e.forward_t(states)
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "0:0")
-    e0 = diee_amd.Engine(0); e0.load_weights(blob)
-    p0, v0 = e0.forward_t(states)
+    for geom in (14, 6, 3):
+        for a, b in zip(out[geom], out[5]):
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), geom
+    assert (out[5][1][0] == out[5][0][0][:7]).all()
+    pl = diee_amd.Engine(0); pl.load_weights(blob); pl.set_options(tower_table="none", tower_cl="none")      # per-layer kernels, 4 boards x 128 channels
+    p0, v0 = pl.forward_t(states)
+    assert pl.last_dispatch()[0][0].startswith("k_conv3x3")
+    pl.close()
+    p, v = out[5][0]
     assert np.abs(p - p0).max() < 2e-5 and np.abs(v - v0).max() < 5e-3
-    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:32]))
-    assert np.abs(p[:32] - rp).max() <= POLICY_ATOL and np.abs(v[:32] - rv).max() <= VALUE_ATOL
-    assert (np.abs(p[:32] - rp) / rp).max() < 0.02
-    # row independence within the geometry
-    p2, v2 = e.forward_t(states[::-1].copy())
-    assert (p2[::-1] == p).all() and (v2[::-1] == v).all()
-    e.close(); e0.close()
+    rp, rv, _ = forward_t(parse(blob), oracle.planes_batch(states[:40]))
+    for q, w in ((p, v), (p0, v0)):
+        assert np.abs(q[:40] - rp).max() <= POLICY_ATOL and np.abs(w[:40] - rv).max() <= VALUE_ATOL
+        assert (np.abs(q[:40] - rp) / rp).max() < 0.02
+    with pytest.raises(diee_amd.DieeError):                      # a geometry of the development build only is refused, not silently replaced
+        e = diee_amd.Engine(0); e.load_weights(blob); e.set_option("tower_table", "0:8")
 
 
 def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
@@ -168,7 +134,7 @@ def test_cluster_tower_equals_layer_by_layer(oracle, monkeypatch):
     blob = diee_amd.random_weights(0)
     states = oracle.random_walk_states(29, 10)[:300]
     assert len(states) == 300
-    monkeypatch.setenv("DIEE_TOWER_TABLE", "928:8,416:6,256:3")
+    monkeypatch.setenv("DIEE_TOWER_TABLE", "928:5,416:6,256:3")
     monkeypatch.setenv("DIEE_TOWER_CL", "none")
     ref = diee_amd.Engine(0); ref.load_weights(blob)
     monkeypatch.setenv("DIEE_TOWER_CL", "32:1,64:2,128:4,256:8")
@@ -290,7 +256,7 @@ def test_every_dispatched_kernel_matches_fp32_on_1024_states(setup, ref1024, lo,
 
 def test_the_searchs_compacted_and_tail_launches_are_of_the_tolerance_tested_families(setup, oracle):
     """what a SEARCH launches beyond the plain dispatch: above 256 live games the compacted evaluation (fused 16x16x32 family and the
-    pair tower, picked per workgroup from the device-side row count), in the tail of a batch the cluster tower <1, 8> with its rows
+    pair tower, picked per workgroup from the device-side row count), in the tail of a batch the cluster towers <1, 8> / <2, 8> / <4, 8> with their rows
     counted on the device -- both named by the probe after a search"""
     import diee_amd
     e, _, _ = setup
@@ -299,8 +265,9 @@ def test_the_searchs_compacted_and_tail_launches_are_of_the_tolerance_tested_fam
     e.alpha_mcts_parallel(walk[:700], cfg, 1, 0, np.arange(700, dtype=np.uint32), np.zeros(700, dtype=np.uint32), ref_quirks=True)
     (k, boards), = e.last_dispatch()
     assert k.startswith("k_tower16 (compacted") and boards == 700
-    e.alpha_mcts_parallel(walk[:6], cfg, 1, 0, np.arange(6, dtype=np.uint32), np.zeros(6, dtype=np.uint32), ref_quirks=True)
-    assert e.last_dispatch() == [("k_tower_cl<1, 8>", 32)]
+    for n, launch in ((3, ("k_tower_cl<1, 8>", 32)), (6, ("k_tower_cl<2, 8>", 64)), (40, ("k_tower_cl<4, 8>", 128))):
+        e.alpha_mcts_parallel(walk[:n], cfg, 1, 0, np.arange(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32), ref_quirks=True)
+        assert e.last_dispatch() == [launch], n
 
 
 def test_engine_matches_the_golden_nn_fixture(oracle):

@@ -1,4 +1,4 @@
-"""The tail of a batch (<= 16 live games; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
+"""The tail of a batch (<= 64 live games; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
 launch for as long as every selected leaf's evaluation is at hand, and the launches in between carry speculative rows.  Nothing of
 that may show in a result: every case here holds the engine -- with the path on, with it off, and with the speculation alone off --
 to the CPU oracle's lockstep search BIT FOR BIT, and asserts that the path really ran (`tail_iterations`) and really saved launches."""
@@ -44,7 +44,8 @@ def roots_of(oracle, n, pick):
 
 @pytest.mark.parametrize("quirks", [1, 0])
 @pytest.mark.parametrize("n,iters,pick", [(1, 100, "mid"), (1, 100, "late"), (2, 100, "mixed"), (3, 64, "late"), (5, 100, "mixed"),
-                                          (8, 100, "mid"), (16, 100, "mixed"), (16, 48, "late"), (4, 400, "mixed")])
+                                          (8, 100, "mid"), (16, 100, "mixed"), (16, 48, "late"), (4, 400, "mixed"),
+                                          (24, 100, "mixed"), (33, 60, "mid"), (48, 100, "late"), (64, 100, "mixed")])
 def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     states = roots_of(oracle, n, pick)
     assert len(states) == n
@@ -71,8 +72,34 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     assert d["tail_spec_rows"] == 0 and d["tail_launches"] <= iters          # no speculation: a launch per iteration that evaluates anything, none for idle ones
     assert t["tail_launches"] <= d["tail_launches"]
     if pick != "late":
-        assert t["tail_spec_rows"] > 0 and t["tail_launches"] < 0.6 * iters, (t["tail_launches"], iters)   # the speculation pays
+        assert t["tail_spec_rows"] > 0 and t["tail_launches"] < (0.6 if n <= 16 else 0.85) * iters, (t["tail_launches"], iters)   # the speculation pays
     assert t["nn_rows"] >= t["tail_spec_rows"]
+
+
+@pytest.mark.parametrize("opts", [dict(spec_rows64_from=1, spec_rows128_from=2), dict(spec_rows64_from=65, spec_rows128_from=65),
+                                  dict(spec_rows64_from=3, spec_rows128_from=65), dict(spec_max_games=7)])
+def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
+    """a tail launch carries 32, 64 or 128 rows depending on the live games (k_tower_cl<1, 8> / <2, 8> / <4, 8>: one arithmetic per row):
+    whatever the thresholds say, and wherever the path hands over to the launch-per-iteration search, the same bits"""
+    n, iters = 9, 48
+    states = roots_of(oracle, n, "mixed")
+    ocfg, gcfg = cfgs(oracle, iters)
+    gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 4
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 2, gids, rds, 1)
+    eng.set_options(**opts)
+    try:
+        r = eng.alpha_mcts_parallel(states, gcfg, SEED, 2, gids, rds, ref_quirks=True)
+        rows = eng.last_dispatch()
+    finally:
+        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=64)
+    assert r["probs"].tobytes() == probs.tobytes()
+    for key in KEYS:
+        assert r["stats"][key] == ostats.as_dict()[key], key
+    want = {1: ("k_tower_cl<4, 8>", 128), 65: ("k_tower_cl<1, 8>", 32), 3: ("k_tower_cl<2, 8>", 64)}.get(opts.get("spec_rows64_from"))
+    if want:
+        assert rows == [want] and r["stats"]["tail_iterations"] == iters
+    else:
+        assert r["stats"]["tail_iterations"] == 0                    # 9 games > spec_max_games = 7: one launch per iteration
 
 
 def test_tail_self_play_whole_games_bit_exact(eng, oracle):
