@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r04w_mfma_busy.json", "r04w_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 4: the 4-wave fused tower)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r04w_pmc_traffic.json", "r04w_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r05h_mfma_busy.json", "r05h_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 5; the 32-board pass with DIEE_SPEC_EVAL=0)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = "r05h_pmc_traffic.json", "r05h_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
 
 
 def host_cores():
@@ -639,6 +639,11 @@ def main(argv=None, engine_factory=None):
             out["value_hbm_only"] = hbm["games"] / hbm["seconds"]
             out["value_delivered_same_seeds"] = hbm["games"] / sum(step_s[:hbm["steps"]])      # (N > 1: on rank 0's clock)
             out["output_delivery_ms"] = sum(hbm["same_seed_delta_ms"]) / len(hbm["same_seed_delta_ms"])
+            # (a same-seed difference of two ~9 s runs: inside +-15 ms it is run-to-run noise, and it can come out negative)
+            out["output_delivery_ms_per_batch"] = hbm["same_seed_delta_ms"]
+            out["output_delivery_note"] = ("same-seed delivered - HBM-only time, one value per repeated batch; |x| < ~15 ms is noise.  `value` times the call as a host "
+                                           "binding of the C ABI makes it (records in engine-owned page-locked arrays, looked at, handed back); the Python binding's "
+                                           "default copy=True adds one host memcpy of the records (~645 MB per batch) on the consumer's side, outside `value`")
             out["output_delivery"].update(hbm_only_steps=hbm["steps"], same_seed_delta_ms=hbm["same_seed_delta_ms"],
                                           delivered_over_hbm_only=(hbm["seconds"] / hbm["steps"]) / (sum(step_s[:hbm["steps"]]) / hbm["steps"]))
         if affinity is not None:

@@ -201,6 +201,8 @@ class AlphaZero:
             raise ValueError(f"train backend {backend!r}: fp32 (default) or bf16")
         self.train_backend = "bf16" if backend in ("bf16", "engine") and on_gpu and game is BACKGAMMON else "fp32"
         self.model.engine_tower = self.train_backend == "bf16"
+        if self.train_backend == "bf16":
+            self.log("[train] opt-in bf16 training step (the tower on the engine's MFMA kernels); the default, like the reference, is fp32")
         # the whole step (forward, backward, Adam) replayed as one HIP graph for full batches (single-rank training only)
         self.use_graph = on_gpu and world == 1 and os.environ.get("DIEE_TRAIN_GRAPH", "1") != "0"
         self._graph = None

@@ -704,6 +704,20 @@ __device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uin
     return ncand;
 }
 
+// development builds (-DDIEE_TAIL_STAMPS): shader-clock sums per phase of k_tail, read by scripts/tail_phases.py
+#ifdef DIEE_TAIL_STAMPS
+__device__ unsigned long long g_tail_stamps[8];     // 0 take-in, 1 meeting (wait for the other games), 2 iteration body, 3 plan (virtual descents + rows), 6 iterations, 7 launches
+#define TL_STAMP(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_tail_stamps[i], tn_ - tl_prev_); tl_prev_ = __builtin_readcyclecounter(); } while (0)
+#define TL_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_tail_stamps[i], 1ull); } while (0)
+extern "C" int diee_dev_tail_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define TL_STAMP(i) do {} while (0)
+#define TL_COUNT(i) do {} while (0)
+#endif
 struct TailArgs { Tail L; uint32_t q; };
 __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n, SearchParams P, float c, TailArgs A) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
@@ -715,6 +729,10 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     const Tail& L = A.L;
     const int lane = threadIdx.x;
     if (L.state[1] != 0u) return;                           // the search is complete: launches the host sent ahead have nothing to do
+#ifdef DIEE_TAIL_STAMPS
+    unsigned long long tl_prev_ = __builtin_readcyclecounter();
+#endif
+    TL_COUNT(7);
     uint32_t it = L.state[0];
     const size_t base = (size_t)slot * T.node_cap;
     uint32_t* crow = L.crow + (size_t)slot * T.node_cap;
@@ -736,6 +754,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         }
         __syncthreads();
     }
+    TL_STAMP(0);
     ExpandScratch& sc = *reinterpret_cast<ExpandScratch*>(tail_smem);
     bool lterm = false, hit = false;
     uint32_t leaf = 0, misses = 0;
@@ -748,12 +767,14 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
             if (lane == 0) { L.state[1] = 2u; L.host[1] = 2u; __threadfence_system(); }
             return;
         }
+        TL_STAMP(1);
         if (misses != 0u) break;
         const uint32_t ring = lterm ? 0u : cr - 1u;
         expand_body<false, 0, true>(T, S, G, n, it, P, it + 1 < L.iterations ? it + 1 : kNoNext, c, slot, sc,
                                     NetRow{L.logits + (size_t)ring * 1352, L.hv + (size_t)ring * 72});
         ++it;
         __syncthreads();                                    // lane 0's selection record before the whole wave reads it
+        TL_STAMP(2); TL_COUNT(6);
         if (it >= L.iterations) break;
     }
     const bool done = it >= L.iterations;
@@ -783,6 +804,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
             if (ncand) atomicAdd(&L.state[3], ncand);
         }
     }
+    TL_STAMP(3);
     if (slot == 0 && lane == 0) {
         L.state[0] = it; L.state[1] = done ? 1u : 0u;
         if (!done) L.state[2] += 1u;

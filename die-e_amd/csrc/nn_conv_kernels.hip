@@ -364,7 +364,10 @@ static constexpr int conv_lds_bytes() {
 template <int C_IN, int MODE, int GT, int NW>
 static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
                         uint16_t* out, float* out_v, int G, int N) {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {};
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int lds = conv_lds_bytes<C_IN, GT, NW * 32>();
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_conv3x3<C_IN, MODE, GT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -378,7 +381,10 @@ static void conv_launch(hipStream_t st, const uint16_t* act, const void* wpack, 
 template <int MODE, int GT, int NSPLIT = 4>
 static void conv_sk_launch(hipStream_t st, const uint16_t* act, const void* wpack, const float* bias, const uint16_t* res,
                            uint16_t* out, int G, int N, float* out_v = nullptr) {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {};
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int rows = GT * 24, mf = (rows + 31) / 32;
     constexpr int lds_a = (rows + 1) * 528 + 16 * 34 + 64, lds_p = NSPLIT * mf * 32 * (32 * 4 + 16);
     constexpr int lds = lds_a > lds_p ? lds_a : lds_p;

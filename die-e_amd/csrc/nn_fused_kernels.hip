@@ -500,7 +500,10 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
 // 1: 2 boards x (8 waves x 1 N-fragment, 18 weight fragments in flight) for mid-size batches
 template <int GT, int NF, int PF>
 static void tower_launch(hipStream_t st, const uint16_t* x_in, const void* wt, const float* bias, uint16_t* x_out, int G) {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {};
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {
@@ -517,7 +520,10 @@ static void tower16_launch(hipStream_t st, const uint16_t* x_in, const void* wt,
                            const void* states = nullptr, const void* winit16 = nullptr, const float* binit = nullptr,
                            const void* whead16 = nullptr, const float* bhead = nullptr, uint16_t* hp = nullptr, float* hv = nullptr,
                            const RowMap rm = RowMap{nullptr, nullptr, 0, 0}) {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {};
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {

@@ -404,7 +404,10 @@ template <int GT, int PF>
 static void tower16p_launch(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                             const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err,
                             const RowMap rm = RowMap{nullptr, nullptr, 0, 0}) {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {};
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int tile = ((GT * 24 + 1) * 528 + 16 * 34 + 128 + 15) / 16 * 16;
     constexpr int lds = 2 * tile;
     if (!attr_set) {

@@ -759,7 +759,10 @@ __global__ __launch_bounds__(256) void k_wgrad_fold(const float* __restrict__ pa
 
 size_t wgrad_scratch_floats() { return (size_t)kWgSplit * 9 * 256 * 256; }
 void launch_wgrad3x3(hipStream_t st, const uint16_t* x, const uint16_t* dy, float* partial, float* dw, int boards) {
-    static bool attr_set = false;                       // (idempotent: a race sets the same attribute twice)
+    static bool attr_set_dev[16] = {};                       // (idempotent: a race sets the same attribute twice)
+    int attr_dev = 0;
+    (void)hipGetDevice(&attr_dev);
+    bool& attr_set = attr_set_dev[attr_dev & 15];             // per device: a ctx on another GPU of this process sets it there too
     constexpr int lds = kWgXBytes + kWgYBytes;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
     hipLaunchKernelGGL(k_wgrad3x3, dim3(16, kWgSplit), dim3(512), lds, st, x, dy, partial, boards * 24);

@@ -1,5 +1,5 @@
-"""AlphaZero.train (the learn loop's training leg) on synthetic fragments: ms per 256-sample step for the three backends
-DIEE_TRAIN=torch | engine (eager) | engine + HIP graph (default)."""
+"""AlphaZero.train (the learn loop's training leg) on synthetic fragments: ms per 256-sample step for the all-PyTorch fp32 step
+(DIEE_TRAIN=fp32: the default, the reference's arithmetic) and the opt-in bf16 step on the engine's kernels (DIEE_TRAIN=bf16), eager and as a HIP graph."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,9 +11,9 @@ n = 256 * steps
 rng = np.random.default_rng(0)
 ps = rng.random((n, 1352), dtype=np.float32); ps /= ps.sum(1, keepdims=True)
 mem = {"state": rng.integers(-3, 4, size=(n, 144)).astype(np.float32), "ps": ps, "outcome": rng.choice([-1, 1], size=n).astype(np.int8)}
-for name, env in (("torch fp32 (MIOpen), fused Adam", {"DIEE_TRAIN": "torch", "DIEE_TRAIN_GRAPH": "0"}),
-                  ("engine tower kernels, eager", {"DIEE_TRAIN": "engine", "DIEE_TRAIN_GRAPH": "0"}),
-                  ("engine tower kernels, HIP graph", {"DIEE_TRAIN": "engine", "DIEE_TRAIN_GRAPH": "1"})):
+for name, env in (("fp32 (default): all-PyTorch step (MIOpen), fused Adam", {"DIEE_TRAIN": "fp32", "DIEE_TRAIN_GRAPH": "0"}),
+                  ("opt-in bf16 step on the engine's tower kernels, eager", {"DIEE_TRAIN": "bf16", "DIEE_TRAIN_GRAPH": "0"}),
+                  ("opt-in bf16 step on the engine's tower kernels, HIP graph", {"DIEE_TRAIN": "bf16", "DIEE_TRAIN_GRAPH": "1"})):
     os.environ.update(env)
     a = az.AlphaZero(None, az.AlphaZeroConfig(1.25, 1, 1, 1, 256, 1024), diee_amd.MctsConfig.default(100), az.OptimizerParams(1e-4, 1e-3),
                      blob=diee_amd.random_weights(0), train_device="cuda", quiet=True)
