@@ -275,11 +275,15 @@ struct TwoScratch {
 // The body of one (slot, iteration): k_expand runs it once per launch; k_tail (the tail of a batch, below) runs it in a loop with the
 // network row taken from its cache of earlier evaluations (TAIL: `nr` points at the slot's row, rows are counted where they are planned).
 struct NetRow { const float* logits; const float* hv; };
+// (k_tail requests its row -- 22 logits per lane, the value features -- BEFORE it meets the other games: the round trip to where the tower
+// launch left them passes while the wave would wait anyway)
+struct NetRowLoaded { ValueHeadIn vh; float lg[22]; };
 template <bool PRE, int TWO>
 using ExpandScratchOf = typename std::conditional<(TWO != 0), TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type;
 template <bool PRE, int TWO = 0, bool TAIL = false>
 __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                                            uint32_t next_it, float c, uint32_t slot, ExpandScratchOf<PRE, TWO>& sc_all, NetRow nr) {
+                                            uint32_t next_it, float c, uint32_t slot, ExpandScratchOf<PRE, TWO>& sc_all, NetRow nr,
+                                            const NetRowLoaded* pre = nullptr) {
     static_assert(PRE || !TWO, "two waves: the second one is the growth");
     static_assert(!TAIL || (!PRE && !TWO), "the tail loop runs the one-wave body");
     auto& sc = [&]() -> auto& { if constexpr (TWO) return sc_all.s; else return sc_all; }();
@@ -331,9 +335,12 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
     const unsigned long long evals0 = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
     const uint32_t node = lterm ? 0u : leaf;
     const uint32_t m0 = lterm ? 0u : m0q;
-    const ValueHeadIn vh = value_head_load(TAIL ? nr.hv : S.hv + (size_t)row * 72, S.wv, lane);
+    const ValueHeadIn vh = (TAIL && pre) ? pre->vh : value_head_load(TAIL ? nr.hv : S.hv + (size_t)row * 72, S.wv, lane);
     float lg[22];
-    if (TWO != 2 || !main_wave) softmax_load(TAIL ? nr.logits : S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
+    if (TAIL && pre) {
+#pragma unroll
+        for (int q = 0; q < 22; ++q) lg[q] = pre->lg[q];
+    } else if (TWO != 2 || !main_wave) softmax_load(TAIL ? nr.logits : S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
     else {
 #pragma unroll
         for (int q = 0; q < 22; ++q) lg[q] = 0.0f;
@@ -346,7 +353,8 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
 #ifndef DIEE_STAGE_L0
 #define DIEE_STAGE_L0 0        // measured: +0.2 us per launch (the seven extra loads per lane cost more than the round trip they save; profiles/r03i_*): off
 #endif
-    l0.valid = (DIEE_STAGE_L0 == 1 || (DIEE_STAGE_L0 == 2 && TWO == 2 && main_wave)) && !root && next_it != kNoNext;
+    // (in the tail, TAIL, the wave is alone on its CU and every round trip of the descent is on the critical path: staged)
+    l0.valid = (TAIL || DIEE_STAGE_L0 == 1 || (DIEE_STAGE_L0 == 2 && TWO == 2 && main_wave)) && !root && next_it != kNoNext;
     {
         const size_t c0 = base + 1 + (l0.valid ? lane : 0);
         l0.vis = T.visits[c0]; l0.val = T.value[c0]; l0.pr = T.prior[c0]; l0.cm = T.meta[c0]; l0.cf = T.first_child[c0];
@@ -763,15 +771,18 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         leaf = S.leaf[slot];
         const uint32_t cr = lterm ? 0u : crow[leaf];
         hit = lterm || cr != 0u;
+        const uint32_t ring = (lterm || cr == 0u) ? 0u : cr - 1u;
+        NetRowLoaded pre;                                   // requested now, used behind the meeting
+        pre.vh = value_head_load(L.hv + (size_t)ring * 72, S.wv, lane);
+        softmax_load(L.logits + (size_t)ring * 1352, lane, pre.lg);
         if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {              // timed out: the host repeats the search launch by launch
             if (lane == 0) { L.state[1] = 2u; L.host[1] = 2u; __threadfence_system(); }
             return;
         }
         TL_STAMP(1);
         if (misses != 0u) break;
-        const uint32_t ring = lterm ? 0u : cr - 1u;
         expand_body<false, 0, true>(T, S, G, n, it, P, it + 1 < L.iterations ? it + 1 : kNoNext, c, slot, sc,
-                                    NetRow{L.logits + (size_t)ring * 1352, L.hv + (size_t)ring * 72});
+                                    NetRow{L.logits + (size_t)ring * 1352, L.hv + (size_t)ring * 72}, &pre);
         ++it;
         __syncthreads();                                    // lane 0's selection record before the whole wave reads it
         TL_STAMP(2); TL_COUNT(6);
