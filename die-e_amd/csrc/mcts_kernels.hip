@@ -272,20 +272,17 @@ struct TwoScratch {
 // TWO == 2 (with PRE, the children exist already): wave 1 is the COMMIT wave -- softmax over the logits row, masked priors of the children --
 // while wave 0 evaluates the value head, backpropagates and descends; same meeting point, wave 1 hands the leaf's new header over in LDS and
 // wave 0 stores it (the descent may be reading that header: nobody else may change it under its feet).
-// The body of one (slot, iteration): k_expand runs it once per launch; k_tail (the tail of a batch, below) runs it in a loop with the
-// network row taken from its cache of earlier evaluations (TAIL: `nr` points at the slot's row, rows are counted where they are planned).
-struct NetRow { const float* logits; const float* hv; };
-// (k_tail requests its row -- 22 logits per lane, the value features -- BEFORE it meets the other games: the round trip to where the tower
-// launch left them passes while the wave would wait anyway)
+// The body of one (slot, iteration) of k_expand.  (k_tail, the tail of a batch, below, runs the same operations in the same order on an
+// LDS copy of the tree: what one changes in the arithmetic the other must follow -- tests/test_tail_gpu.py holds both to the oracle.)
+// k_tail requests its network row -- 22 logits per lane, the value features -- BEFORE it meets the other games: the round trip to where
+// the tower launch left them passes while the wave would wait anyway
 struct NetRowLoaded { ValueHeadIn vh; float lg[22]; };
 template <bool PRE, int TWO>
 using ExpandScratchOf = typename std::conditional<(TWO != 0), TwoScratch, typename std::conditional<PRE, SettleScratch, ExpandScratch>::type>::type;
-template <bool PRE, int TWO = 0, bool TAIL = false>
+template <bool PRE, int TWO = 0>
 __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
-                                            uint32_t next_it, float c, uint32_t slot, ExpandScratchOf<PRE, TWO>& sc_all, NetRow nr,
-                                            const NetRowLoaded* pre = nullptr) {
+                                            uint32_t next_it, float c, uint32_t slot, ExpandScratchOf<PRE, TWO>& sc_all) {
     static_assert(PRE || !TWO, "two waves: the second one is the growth");
-    static_assert(!TAIL || (!PRE && !TWO), "the tail loop runs the one-wave body");
     auto& sc = [&]() -> auto& { if constexpr (TWO) return sc_all.s; else return sc_all; }();
     if (slot >= n) return;
     if constexpr (TWO == 1) {
@@ -335,12 +332,9 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
     const unsigned long long evals0 = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
     const uint32_t node = lterm ? 0u : leaf;
     const uint32_t m0 = lterm ? 0u : m0q;
-    const ValueHeadIn vh = (TAIL && pre) ? pre->vh : value_head_load(TAIL ? nr.hv : S.hv + (size_t)row * 72, S.wv, lane);
+    const ValueHeadIn vh = value_head_load(S.hv + (size_t)row * 72, S.wv, lane);
     float lg[22];
-    if (TAIL && pre) {
-#pragma unroll
-        for (int q = 0; q < 22; ++q) lg[q] = pre->lg[q];
-    } else if (TWO != 2 || !main_wave) softmax_load(TAIL ? nr.logits : S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
+    if (TWO != 2 || !main_wave) softmax_load(S.logits + (size_t)row * 1352, lane, lg);     // (TWO == 2: the logits are the commit wave's business)
     else {
 #pragma unroll
         for (int q = 0; q < 22; ++q) lg[q] = 0.0f;
@@ -353,8 +347,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
 #ifndef DIEE_STAGE_L0
 #define DIEE_STAGE_L0 0        // measured: +0.2 us per launch (the seven extra loads per lane cost more than the round trip they save; profiles/r03i_*): off
 #endif
-    // (in the tail, TAIL, the wave is alone on its CU and every round trip of the descent is on the critical path: staged)
-    l0.valid = (TAIL || DIEE_STAGE_L0 == 1 || (DIEE_STAGE_L0 == 2 && TWO == 2 && main_wave)) && !root && next_it != kNoNext;
+    l0.valid = (DIEE_STAGE_L0 == 1 || (DIEE_STAGE_L0 == 2 && TWO == 2 && main_wave)) && !root && next_it != kNoNext;
     {
         const size_t c0 = base + 1 + (l0.valid ? lane : 0);
         l0.vis = T.visits[c0]; l0.val = T.value[c0]; l0.pr = T.prior[c0]; l0.cm = T.meta[c0]; l0.cf = T.first_child[c0];
@@ -391,7 +384,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
     if (active && main_wave) {
     // batch rows pushed through the ResNet for this batch (one writer per batch and launch)
     if (slot == seg_first && lane == 0) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals0 + (seg_end - seg_first);
-    if (!TAIL && (root || S.slot_row == nullptr || !lterm)) cn[SC_NN_ROWS] += 1;
+    if (root || S.slot_row == nullptr || !lterm) cn[SC_NN_ROWS] += 1;
 
     if (!root) {
         if (lterm) {
@@ -621,20 +614,11 @@ template <bool PRE, int TWO = 0>
 __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs G, uint32_t n, uint32_t it, SearchParams P,
                                                            uint32_t next_it, float c) {
     __shared__ ExpandScratchOf<PRE, TWO> sc_all;
-    expand_body<PRE, TWO>(T, S, G, n, it, P, next_it, c, blockIdx.x, sc_all, NetRow{nullptr, nullptr});
+    expand_body<PRE, TWO>(T, S, G, n, it, P, next_it, c, blockIdx.x, sc_all);
 }
 
 // ---- the tail of a batch: iterations in a loop, network rows from the ring (search_types.h, Tail) ---------------------------------
 constexpr int kTailSpin = 1 << 20;
-// LDS of k_tail: the one-wave expansion's scratch while iterations run; when a launch has to be planned the same bytes hold a scratch
-// copy of the game's tree statistics (five words per node) for the virtual descents, and the candidates they find
-struct TailStage {
-    float vis[kTailLdsNodes], val[kTailLdsNodes], pri[kTailLdsNodes], cval[kTailLdsNodes];
-    uint32_t meta[kTailLdsNodes], fc[kTailLdsNodes], crow[kTailLdsNodes];
-    uint32_t cand[64];
-};
-constexpr size_t kTailLds = sizeof(TailStage) > sizeof(ExpandScratch) ? sizeof(TailStage) : sizeof(ExpandScratch);
-
 // the games' workgroups meet: every one has published its selection of iteration `it` (flags, selection record) and says whether its
 // leaf has its evaluation; returns the number of workgroups that said no.  One word per meeting, never reused within a move-step.
 __device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, int lane, uint32_t* err, uint32_t& misses) {
@@ -657,61 +641,6 @@ __device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, 
     return v != 0xffffffffu;
 }
 
-// Virtual descents: the search's own selection rule (select_slot: q + c * sqrt(N) / (n + 1) * p, last of equal maxima) run ahead on a
-// scratch copy of the statistics.  An evaluation that is not known yet counts as 0 (a random-init net's values are small; the
-// pricing run found the parent's mean no better), a known one as its value, a finished game as +-1 for the root's player
-// (alpha_mcts.rs:157-163); the unexpanded nodes the descents end on, not evaluated yet, are the candidates.  Heuristic only: which
-// rows a launch carries beside the demanded ones never shows in a result.
-__device__ __forceinline__ uint32_t tail_rollout(const Tree& T, size_t base, uint32_t used, const uint32_t* __restrict__ crow, const float* __restrict__ cval,
-                                                 TailStage& st, int lane, float c, uint32_t want, uint32_t max_steps, uint32_t demanded, int root_player) {
-    const uint32_t nl = used < kTailLdsNodes ? used : kTailLdsNodes;
-    for (uint32_t i = lane; i < nl; i += 64) {
-        st.vis[i] = T.visits[base + i]; st.val[i] = T.value[base + i]; st.pri[i] = T.prior[base + i];
-        st.meta[i] = T.meta[base + i]; st.fc[i] = T.first_child[base + i];
-        st.crow[i] = crow[i]; st.cval[i] = cval[i];
-    }
-    __syncthreads();
-    uint32_t ncand = 0, fruitless = 0;
-    for (uint32_t step = 0; step < max_steps && ncand < want && fruitless < 8; ++step) {
-        uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
-        for (;;) {
-            mt = node < nl ? st.meta[node] : T.meta[base + node];
-            const uint32_t k = meta_nch(mt);
-            if (k == 0) break;
-            const uint32_t fc = node < nl ? st.fc[node] : T.first_child[base + node];
-            const float sq = sqrtf(node < nl ? st.vis[node] : T.visits[base + node]);
-            Best b{0.0f, -1};
-            for (uint32_t j = lane; j < k; j += 64) {
-                const uint32_t ci = fc + j;
-                const float vis = ci < nl ? st.vis[ci] : T.visits[base + ci], val = ci < nl ? st.val[ci] : T.value[base + ci];
-                const float pr = ci < nl ? st.pri[ci] : T.prior[base + ci];
-                const float q = vis == 0.0f ? 0.0f : val / vis;
-                const float s = q + (c * (sq / (vis + 1.0f))) * pr;
-                if (s == s && (b.j < 0 || !(b.s > s))) { b.s = s; b.j = (int)j; }
-            }
-            b = wave_best(b);
-            node = fc + (uint32_t)(b.j >= 0 ? b.j : (int)k - 1);
-            ++depth;
-            if ((uint32_t)lane == depth) mine = node;
-            if (depth >= 63) break;
-        }
-        // the leaf: a finished game (bits of its header, set when it was created), an evaluation at hand, or a candidate -- no trip to memory
-        const uint32_t cr = node < nl ? st.crow[node] : crow[node];
-        float x = 0.0f;
-        bool fresh = false;
-        if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
-        else if (cr != 0) x = node < nl ? st.cval[node] : cval[node];
-        else if (!(mt & kDrained) && node != demanded) {
-            const bool dup = __ballot((uint32_t)lane < ncand && st.cand[lane] == node) != 0ull;
-            fresh = !dup;
-        }
-        if (fresh) { if (lane == 0) st.cand[ncand] = node; ++ncand; fruitless = 0; } else ++fruitless;
-        if ((uint32_t)lane <= depth && mine < nl) { st.vis[mine] += 1.0f; st.val[mine] += x; }
-        __syncthreads();
-    }
-    return ncand;
-}
-
 // development builds (-DDIEE_TAIL_STAMPS): shader-clock sums per phase of k_tail, read by scripts/tail_phases.py
 #ifdef DIEE_TAIL_STAMPS
 __device__ unsigned long long g_tail_stamps[8];     // 0 take-in, 1 meeting (wait for the other games), 2 iteration body, 3 plan (virtual descents + rows), 6 iterations, 7 launches
@@ -727,26 +656,102 @@ extern "C" int diee_dev_tail_stamps(unsigned long long* out, int reset) {
 #define TL_COUNT(i) do {} while (0)
 #endif
 struct TailArgs { Tail L; uint32_t q; };
+
+// ---- k_tail: the iterations of a search in a loop, the tree's statistics in LDS ("UCB selection staged in LDS") ---------------------
+// The first version of this kernel ran expand_body, k_expand's code, once per iteration: every level of the descent, the
+// backpropagation and a dozen words of per-slot state were round trips to the L2 (~1 us each for a wave alone on its CU: 60 % of the
+// ~11 us of an iteration, profiles/r05m_tail_body_phases.txt; 111.4 -> 112.5 games/s with this one on the same box, profiles/r05o_*).
+// k_tail keeps what an iteration reads again in the CU: the statistics and headers of the
+// game's nodes (visits, value, prior, header words, the ring row and value of evaluated nodes: 28 bytes per node, kTailLdsNodes
+// nodes) in LDS -- loaded when a launch starts, every update also written through to HBM (nodes past the capacity are read and
+// written there) --, and the selection record, the path of the last selection, the counters and the arena's fill mark in registers
+// from one iteration to the next.  A descent is LDS reads; the leaf's 32-byte state and its ring row are requested BEFORE the games
+// meet.  The arithmetic is select_slot's / expand_body's, operation for operation, in the same order per node.
+struct TailTree {
+    float vis[kTailLdsNodes], val[kTailLdsNodes], pri[kTailLdsNodes], cval[kTailLdsNodes];
+    uint32_t meta[kTailLdsNodes], fc[kTailLdsNodes], crow[kTailLdsNodes];
+};
+struct TailLds {
+    TailTree t;
+    float vvis[kTailLdsNodes], vval[kTailLdsNodes];          // the virtual descents' scratch copy of visits / value
+    WaveScratch ws;
+    float lgs[22 * 64];
+    float raw[kMaxPlays];
+    uint16_t code[kMaxPlays];
+    uint32_t cand[64];
+};
+static_assert(sizeof(TailLds) <= 160 * 1024, "one workgroup per CU");
+
+// the tree through LDS: nodes below kTailLdsNodes live there (and in HBM, written through), the others in HBM alone
+struct TreeLds {
+    const Tree& T; size_t base; TailTree& t;
+    __device__ __forceinline__ float vis(uint32_t i) const { return i < kTailLdsNodes ? t.vis[i] : T.visits[base + i]; }
+    __device__ __forceinline__ float val(uint32_t i) const { return i < kTailLdsNodes ? t.val[i] : T.value[base + i]; }
+    __device__ __forceinline__ float pri(uint32_t i) const { return i < kTailLdsNodes ? t.pri[i] : T.prior[base + i]; }
+    __device__ __forceinline__ uint32_t meta(uint32_t i) const { return i < kTailLdsNodes ? t.meta[i] : T.meta[base + i]; }
+    __device__ __forceinline__ uint32_t fc(uint32_t i) const { return i < kTailLdsNodes ? t.fc[i] : T.first_child[base + i]; }
+    __device__ __forceinline__ void add(uint32_t i, float v) const {          // visits += 1, value += v (simple_mcts.rs:96-103, one node)
+        const float nv = vis(i) + 1.0f, nw = val(i) + v;
+        if (i < kTailLdsNodes) { t.vis[i] = nv; t.val[i] = nw; }
+        T.visits[base + i] = nv; T.value[base + i] = nw;
+    }
+    __device__ __forceinline__ void set_header(uint32_t i, uint32_t m, uint32_t f) const {
+        if (i < kTailLdsNodes) { t.meta[i] = m; t.fc[i] = f; }
+        T.meta[base + i] = m; T.first_child[base + i] = f;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n, SearchParams P, float c, TailArgs A) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
-    // one game per workgroup; up to 32 games all on XCD 0 under round-robin dispatch (grid = 8 n, every eighth block works), more
-    // games spread over the chip (placement is speed only: the workgroups meet through agent-scope atomics)
     uint32_t slot = blockIdx.x;
     if (gridDim.x == 8u * n) { if ((blockIdx.x & 7u) != 0u) return; slot = blockIdx.x >> 3; }
     if (slot >= n) return;
     const Tail& L = A.L;
     const int lane = threadIdx.x;
-    if (L.state[1] != 0u) return;                           // the search is complete: launches the host sent ahead have nothing to do
+    if (L.state[1] != 0u) return;
 #ifdef DIEE_TAIL_STAMPS
     unsigned long long tl_prev_ = __builtin_readcyclecounter();
 #endif
     TL_COUNT(7);
     uint32_t it = L.state[0];
+    TailLds& D = *reinterpret_cast<TailLds*>(tail_smem);
     const size_t base = (size_t)slot * T.node_cap;
-    uint32_t* crow = L.crow + (size_t)slot * T.node_cap;
-    float* cval = L.cval + (size_t)slot * T.node_cap;
-    // ---- take in the rows of tower launch q - 1: which node each evaluated, its value for the virtual descents (any summation
-    // order will do there: an expansion computes its value from the row itself, with the search's own value head) ----
+    uint32_t* crow_g = L.crow + (size_t)slot * T.node_cap;
+    float* cval_g = L.cval + (size_t)slot * T.node_cap;
+    const TreeLds X{T, base, D.t};
+    const bool quirks = P.quirks != 0;
+    // ---- what the slot carries from launch to launch (the record select_slot / k_tail leave in HBM), into registers ----
+    const uint32_t seg = G.n == 1 ? 0u : S.seg[slot];
+    const uint32_t seg_first = G.first_slot[seg], seg_end = G.end_slot[seg];
+    const unsigned long long seed = G.seed[seg];
+    const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
+    const float rv0 = S.root_value0[seg];
+    unsigned long long evals = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
+    uint32_t used = T.used[slot];
+    bool lterm = S.leaf_term[slot] != 0;
+    uint32_t leaf = S.leaf[slot], sel = S.sel[slot], leaf_meta = S.leaf_meta[slot];
+    float sel_value = S.sel_value[slot];
+    uint32_t plen = S.path_len[slot];
+    uint32_t pnode = S.path[(size_t)slot * kPathCap + lane];     // lane d: the node at depth d of the last real selection's path
+    uint32_t cn[SC_COUNT];
+    load_counters(S, slot, cn);
+    const BgState rs = load_state(&T.state[base]);
+    const int root_player = st_player(rs);
+    // every game of the batch held a real selection when the previous launch ended (it never loses it): no slot can still be counted
+    // as a stale INITIAL one (Q14), so the batch's first slot need not look at an iteration's flag words for that
+    bool all_sel = false;
+    if (quirks && slot == seg_first) {
+        const uint32_t g = seg_first + (uint32_t)lane;
+        all_sel = __ballot(g < seg_end && S.sel[g] == kNone) == 0ull && seg_end - seg_first <= 64u;
+    }
+    // ---- the tree's statistics into LDS; the rows of tower launch q - 1 on top ----
+    const uint32_t nl = used < kTailLdsNodes ? used : kTailLdsNodes;
+    for (uint32_t i = lane; i < nl; i += 64) {
+        D.t.vis[i] = T.visits[base + i]; D.t.val[i] = T.value[base + i]; D.t.pri[i] = T.prior[base + i];
+        D.t.meta[i] = T.meta[base + i]; D.t.fc[i] = T.first_child[base + i];
+        D.t.crow[i] = crow_g[i]; D.t.cval[i] = cval_g[i];
+    }
+    __syncthreads();
     if (A.q > 0) {
         const uint32_t pq = A.q - 1, nr = L.n_rows[pq] < L.rows ? L.n_rows[pq] : L.rows;
         for (uint32_t r = lane; r < nr; r += 64) {
@@ -756,65 +761,253 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                 float dot = 0.0f;
                 for (int i = 0; i < 72; ++i) dot += h[i] * S.wv[i];
                 const uint32_t node = rn & 0xFFFFFFu;
-                cval[node] = tanhf(dot + S.wv[72]);
-                crow[node] = pq * L.rows + r + 1u;
+                const float cv = tanhf(dot + S.wv[72]);
+                cval_g[node] = cv; crow_g[node] = pq * L.rows + r + 1u;
+                if (node < kTailLdsNodes) { D.t.cval[node] = cv; D.t.crow[node] = pq * L.rows + r + 1u; }
             }
         }
         __syncthreads();
     }
     TL_STAMP(0);
-    ExpandScratch& sc = *reinterpret_cast<ExpandScratch*>(tail_smem);
-    bool lterm = false, hit = false;
-    uint32_t leaf = 0, misses = 0;
+    BgState lst = load_state(&S.eval_states[slot]);             // the selected leaf's state
+    bool hit = false;
+    uint32_t misses = 0;
     for (;;) {
-        lterm = S.leaf_term[slot] != 0;
-        leaf = S.leaf[slot];
-        const uint32_t cr = lterm ? 0u : crow[leaf];
+        const uint32_t cr = lterm ? 0u : (leaf < kTailLdsNodes ? D.t.crow[leaf] : crow_g[leaf]);
         hit = lterm || cr != 0u;
         const uint32_t ring = (lterm || cr == 0u) ? 0u : cr - 1u;
-        NetRowLoaded pre;                                   // requested now, used behind the meeting
+        NetRowLoaded pre;                                       // requested now, used behind the meeting
         pre.vh = value_head_load(L.hv + (size_t)ring * 72, S.wv, lane);
         softmax_load(L.logits + (size_t)ring * 1352, lane, pre.lg);
-        if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {              // timed out: the host repeats the search launch by launch
+        if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {
             if (lane == 0) { L.state[1] = 2u; L.host[1] = 2u; __threadfence_system(); }
             return;
         }
         TL_STAMP(1);
         if (misses != 0u) break;
-        expand_body<false, 0, true>(T, S, G, n, it, P, it + 1 < L.iterations ? it + 1 : kNoNext, c, slot, sc,
-                                    NetRow{L.logits + (size_t)ring * 1352, L.hv + (size_t)ring * 72}, &pre);
+        // ================= iteration `it` (expand_body<false, 0>'s operations, in its order) =================
+        uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
+        // the flag words matter to a game whose leaf is a finished game (`continue`, stale slot) and to the batch's first slot
+        uint2 ifl = make_uint2(1u, 0u);
+        if (lterm || (quirks && slot == seg_first && !all_sel)) ifl = *(const uint2*)iflag;
+        const bool active = ifl.x != 0u;
+        float v = 0.0f;
+        bool do_expand = !lterm, do_backprop = true;
+        if (active) {
+            if (slot == seg_first) evals += (unsigned long long)(seg_end - seg_first);
+            if (lterm) {
+                do_expand = false; do_backprop = false;
+                if (quirks && sel != kNone) {                   // the stale slot is backpropagated with its own value again (Q14)
+                    if (plen) { if ((uint32_t)lane < plen) X.add(pnode, sel_value); }
+                    else if (lane == 0) { for (uint32_t i = sel; i != kNone; i = T.parent[base + i]) X.add(i, sel_value); }
+                }
+            } else {
+                v = value_head_eval(pre.vh, lane);
+                sel_value = v;
+            }
+            const uint32_t m0 = lterm ? 0u : leaf_meta;
+            if (do_expand && !(m0 & kDrained)) {
+                int k = bg_legal_plays_wave(lst, &D.ws, lane, S.overflow);
+                if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }
+                const int r0 = st_roll(lst, 0), r1 = st_roll(lst, 1);
+                float smM, smInv;
+                softmax_reduce(pre.lg, lane, smM, smInv);
+#pragma unroll
+                for (int q = 0; q < 22; ++q) D.lgs[lane + 64 * q] = pre.lg[q];
+                __syncthreads();
+                for (int j = lane; j < k; j += 64) {
+                    const uint32_t code = bg_encode_dev(r0, r1, D.ws.play[j]);
+                    D.raw[j] = softmax_prob(D.lgs[code], smM, smInv); D.code[j] = (uint16_t)code;
+                }
+                __syncthreads();
+                float pr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[r] = lane + 64 * r < k ? D.raw[lane + 64 * r] : 0.0f;
+                float sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = k - 64 * r < 64 ? k - 64 * r : 64;                    // uniform
+                    for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[r]), j));
+                }
+                const uint32_t first = used;
+                if (first + (uint32_t)k > T.node_cap) {
+                    if (lane == 0) atomicOr(S.overflow, 2u);
+                } else {
+                    const uint32_t e = it + 1u;
+                    for (int j = lane; j < k; j += 64) {
+                        const uint32_t cl = first + (uint32_t)j;
+                        const size_t ci = base + cl;
+                        BgState cs = lst;
+                        int d0, d1;
+                        draw_dice(seed, gid, rnd, e, (uint32_t)j, d0, d1);      // child dice frozen at creation (Q9)
+                        bg_apply_dev(cs, D.ws.play[j], d0, d1);
+                        store_state(&T.state[ci], cs);
+                        const float prj = D.raw[j] / sum;
+                        const uint32_t cm = (uint32_t)D.code[j] | meta_terminal_bits(cs);
+                        T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = prj;
+                        T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = cm;
+                        if (cl < kTailLdsNodes) {
+                            D.t.vis[cl] = 0.0f; D.t.val[cl] = 0.0f; D.t.pri[cl] = prj; D.t.meta[cl] = cm; D.t.fc[cl] = 0; D.t.crow[cl] = 0; D.t.cval[cl] = 0.0f;
+                        }
+                    }
+                    const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+                    if (lane == 0) X.set_header(leaf, nmeta, first);
+                    used = first + (uint32_t)k;
+                    cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
+                    if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
+                }
+                __syncthreads();
+            }
+            if (do_backprop) {
+                if (plen) { if ((uint32_t)lane < plen) X.add(pnode, v); }
+                else if (lane == 0) { for (uint32_t i = leaf; i != kNone; i = T.parent[base + i]) X.add(i, v); }
+            }
+            if (quirks && slot == seg_first && ifl.y != 0u && lane == 0) {
+                // slots still holding the initial 0 index re-backpropagate node 0 = this root with the NN value of its state (Q14)
+                float rvis = X.vis(0), rval = X.val(0);
+                for (uint32_t i = 0; i < ifl.y; ++i) { rvis += 1.0f; rval += rv0; }
+                D.t.vis[0] = rvis; D.t.val[0] = rval; T.visits[base] = rvis; T.value[base] = rval;
+            }
+            __syncthreads();
+        }
+        // ================= selection for iteration it + 1 (select_slot on the LDS copy) =================
+        if (it + 1 < L.iterations) {
+            uint32_t* nflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it + 1);
+            uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone;
+            uint32_t mt = X.meta(0), fcn = X.fc(0);
+            float nvis = X.vis(0);
+            for (;;) {
+                const uint32_t k = meta_nch(mt);
+                if (k == 0) break;
+                const float sq = sqrtf(nvis);
+                Best b{0.0f, -1};
+                int lastnan = -1;
+                for (uint32_t j = lane; j < k; j += 64) {
+                    const uint32_t ci = fcn + j;
+                    const float vis = X.vis(ci), val = X.val(ci), pr = X.pri(ci);
+                    const float q = vis == 0.0f ? 0.0f : val / vis;
+                    const float t = sq / (vis + 1.0f);
+                    const float u = c * t;
+                    const float w = u * pr;
+                    const float sc_ = q + w;
+                    if (sc_ != sc_) lastnan = (int)j;
+                    else if (b.j < 0 || !(b.s > sc_)) { b.s = sc_; b.j = (int)j; }
+                }
+                lastnan = wave_allmax_i32(lastnan);
+                if (lastnan >= 0) {                             // the sequential fold restarts after a NaN: only children after the last NaN compete
+                    b.s = 0.0f; b.j = -1;
+                    for (uint32_t j = lane; j < k; j += 64) {
+                        if ((int)j <= lastnan) continue;
+                        const uint32_t ci = fcn + j;
+                        const float vis = X.vis(ci), val = X.val(ci), pr = X.pri(ci);
+                        const float q = vis == 0.0f ? 0.0f : val / vis;
+                        const float t = sq / (vis + 1.0f);
+                        const float u = c * t;
+                        const float w = u * pr;
+                        const float sc_ = q + w;
+                        if (b.j < 0 || !(b.s > sc_)) { b.s = sc_; b.j = (int)j; }
+                    }
+                }
+                b = wave_best(b);
+                const int chosen = b.j >= 0 ? b.j : lastnan;
+                node = fcn + (uint32_t)chosen;
+                ++depth;
+                if ((uint32_t)lane == depth) mine = node;
+                mt = X.meta(node); fcn = X.fc(node); nvis = X.vis(node);
+            }
+            const uint32_t npl = depth < S.path_cap ? depth + 1u : 0u;
+            cn[SC_SELECTIONS] += 1; cn[SC_DEPTH_SUM] += depth;
+            if (mt & kMetaTerminal) {                           // a finished game: +-1 for the ROOT's player (alpha_mcts.rs:157-163)
+                const float tv = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
+                if (npl) { if ((uint32_t)lane < npl) X.add(mine, tv); }
+                else if (lane == 0) { for (uint32_t i = node; i != kNone; i = T.parent[base + i]) X.add(i, tv); }
+                cn[SC_TERMINAL] += 1;
+                lterm = true;
+                if (lane == 0 && quirks && sel == kNone) atomicAdd(&nflag[1], 1u);
+            } else {
+                lterm = false; leaf = node; sel = node; leaf_meta = mt; plen = npl; pnode = mine;
+                if (lane == 0) nflag[0] = 1u;
+                lst = load_state(&T.state[base + node]);        // in flight while the games meet
+            }
+        }
         ++it;
-        __syncthreads();                                    // lane 0's selection record before the whole wave reads it
+        __syncthreads();
         TL_STAMP(2); TL_COUNT(6);
         if (it >= L.iterations) break;
     }
+    // ---- the record for the next launch (and for whoever reads the slot after the search) ----
+    if (lane == 0) {
+        S.leaf_term[slot] = lterm ? 1 : 0; S.leaf[slot] = leaf; S.sel[slot] = sel; S.leaf_meta[slot] = leaf_meta;
+        S.sel_value[slot] = sel_value; S.path_len[slot] = (uint8_t)plen;
+        T.used[slot] = used;
+        if (slot == seg_first) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals;
+        store_state(&S.eval_states[slot], lst);
+    }
+    if ((uint32_t)lane < plen) S.path[(size_t)slot * kPathCap + lane] = pnode;
     const bool done = it >= L.iterations;
+    uint32_t mine_rows = 0, ncand = 0;
     if (!done) {
-        // ---- plan tower launch q: the leaves without an evaluation, and in the rows that are left what the search is likely to
-        // select next (every game an equal share) ----
+        // ---- plan tower launch q: the leaf without an evaluation, and this game's share of speculative rows.  Virtual descents: the
+        // search's own selection rule (q + c * sqrt(N) / (n + 1) * p, last of equal maxima) run ahead on a scratch copy of visits / value
+        // (everything else of the LDS tree is read in place).  An evaluation that is not known yet counts as 0 (a random-init net's
+        // values are small; the pricing run found the parent's mean no better), a known one as its value, a finished game as +-1 for
+        // the root's player (alpha_mcts.rs:157-163); the unexpanded nodes the descents end on, not evaluated yet, are the candidates.
+        // Heuristic only: which rows a launch carries beside the demanded ones never shows in a result. ----
         const uint32_t room = L.rows - (misses < L.rows ? misses : L.rows);
-        const uint32_t want = room / n + (slot < room % n ? 1u : 0u);
-        TailStage& stg = *reinterpret_cast<TailStage*>(tail_smem);
-        const BgState rs = load_state(&T.state[base]);
-        uint32_t ncand = 0;
-        if (want > 0 && L.rollout_steps > 0)
-            ncand = tail_rollout(T, base, T.used[slot], crow, cval, stg, lane, c, want < 63u ? want : 63u, L.rollout_steps, hit ? kNone : leaf, st_player(rs));
-        const uint32_t mine_rows = (hit ? 0u : 1u) + ncand;
+        const uint32_t want0 = room / n + (slot < room % n ? 1u : 0u), want = want0 < 63u ? want0 : 63u;
+        const uint32_t nu = used < kTailLdsNodes ? used : kTailLdsNodes;
+        if (want > 0 && L.rollout_steps > 0) {
+            for (uint32_t i = lane; i < nu; i += 64) { D.vvis[i] = D.t.vis[i]; D.vval[i] = D.t.val[i]; }
+            __syncthreads();
+            const uint32_t demanded = hit ? kNone : leaf;
+            uint32_t fruitless = 0;
+            for (uint32_t step = 0; step < L.rollout_steps && ncand < want && fruitless < 8; ++step) {
+                uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
+                for (;;) {
+                    mt = X.meta(node);
+                    const uint32_t k = meta_nch(mt);
+                    if (k == 0) break;
+                    const uint32_t fcn = X.fc(node);
+                    const float sq = sqrtf(node < nu ? D.vvis[node] : T.visits[base + node]);
+                    Best b{0.0f, -1};
+                    for (uint32_t j = lane; j < k; j += 64) {
+                        const uint32_t ci = fcn + j;
+                        const float vis = ci < nu ? D.vvis[ci] : T.visits[base + ci], val = ci < nu ? D.vval[ci] : T.value[base + ci];
+                        const float q = vis == 0.0f ? 0.0f : val / vis;
+                        const float sc_ = q + (c * (sq / (vis + 1.0f))) * X.pri(ci);
+                        if (sc_ == sc_ && (b.j < 0 || !(b.s > sc_))) { b.s = sc_; b.j = (int)j; }
+                    }
+                    b = wave_best(b);
+                    node = fcn + (uint32_t)(b.j >= 0 ? b.j : (int)k - 1);
+                    ++depth;
+                    if ((uint32_t)lane == depth) mine = node;
+                    if (depth >= 63) break;
+                }
+                const uint32_t cr = node < kTailLdsNodes ? D.t.crow[node] : crow_g[node];
+                float x = 0.0f;
+                bool fresh = false;
+                if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
+                else if (cr != 0) x = node < kTailLdsNodes ? D.t.cval[node] : cval_g[node];
+                else if (!(mt & kDrained) && node != demanded) fresh = __ballot((uint32_t)lane < ncand && D.cand[lane] == node) == 0ull;
+                if (fresh) { if (lane == 0) D.cand[ncand] = node; ++ncand; fruitless = 0; } else ++fruitless;
+                if ((uint32_t)lane <= depth && mine < nu) { D.vvis[mine] += 1.0f; D.vval[mine] += x; }
+                __syncthreads();
+            }
+        }
+        mine_rows = (hit ? 0u : 1u) + ncand;
         uint32_t start = 0;
         if (lane == 0 && mine_rows) start = atomicAdd(&L.n_rows[A.q], mine_rows);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         if ((uint32_t)lane < mine_rows && start + (uint32_t)lane < L.rows) {
-            const uint32_t node = (!hit && lane == 0) ? leaf : stg.cand[lane - (hit ? 0 : 1)];
+            const uint32_t node = (!hit && lane == 0) ? leaf : D.cand[lane - (hit ? 0 : 1)];
             const uint32_t r = A.q * L.rows + start + (uint32_t)lane;
-            store_state(&L.rows_state[r], (!hit && lane == 0) ? load_state(&S.eval_states[slot]) : load_state(&T.state[base + node]));
+            store_state(&L.rows_state[r], (!hit && lane == 0) ? lst : load_state(&T.state[base + node]));
             L.rows_node[r] = (slot << 24) | node;
         }
-        if (lane == 0) {
-            uint32_t* cnt = S.slot_cnt + slot * SC_COUNT;
-            cnt[SC_NN_ROWS] += mine_rows;                   // rows this game sends through the network (speculative ones included)
-            if (ncand) atomicAdd(&L.state[3], ncand);
-        }
+        cn[SC_NN_ROWS] += mine_rows;
+        if (lane == 0 && ncand) atomicAdd(&L.state[3], ncand);
     }
+    if (lane == 0) store_counters(S, slot, cn);
     TL_STAMP(3);
     if (slot == 0 && lane == 0) {
         L.state[0] = it; L.state[1] = done ? 1u : 0u;
@@ -1186,10 +1379,10 @@ void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 15]) {
-        (void)hipFuncSetAttribute((const void*)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds);
+        (void)hipFuncSetAttribute((const void*)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailLds));
         attr_set[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k_tail, dim3(n <= 32 ? 8 * n : n), dim3(64), kTailLds, st, T, S, G, n, P, c, TailArgs{L, q});
+    hipLaunchKernelGGL(k_tail, dim3(n <= 32 ? 8 * n : n), dim3(64), sizeof(TailLds), st, T, S, G, n, P, c, TailArgs{L, q});
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

@@ -19,7 +19,7 @@ L.diee_dev_tail_stamps.argtypes = [C.c_void_p, C.c_int]; L.diee_dev_tail_stamps.
 e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
 walk = orc.random_walk_states(7, 60)
 cfg = diee_amd.MctsConfig.default(100)
-names = ["take-in of the launch's rows", "meeting (waiting for the other games)", "iteration body (expand_body)", "plan (virtual descents, rows)"]
+names = ["tree into LDS + take-in of the launch's rows", "meeting (waiting for the other games)", "iteration body", "record out + plan (virtual descents, rows)"]
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64]:
     states = walk[100:100 + 5 * n:5]
     gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
