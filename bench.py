@@ -27,8 +27,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r05h_mfma_busy.json", "r05h_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 5; the 32-board pass with DIEE_SPEC_EVAL=0)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r05h_pmc_traffic.json", "r05h_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r05r_mfma_busy.json", "r05r_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 5; the 32-board pass with DIEE_SPEC_EVAL=0)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = "r05r_pmc_traffic.json", "r05r_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
 
 
 def host_cores():
