@@ -203,7 +203,14 @@ def same_gpu_as_torch(device):
     if not hasattr(pr, "pci_bus_id"):
         return True, ours, None
     theirs = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
-    return ours == theirs, ours, theirs
+    # compared as numbers (domain, bus, device): a formatting difference between the two runtimes must not read as another GPU, and an
+    # address this code cannot parse is no evidence of a mismatch
+    import re
+    m = re.fullmatch(r"([0-9a-f]+):([0-9a-f]+):([0-9a-f]+)\.([0-9a-f]+)", ours)
+    if not m:
+        return True, ours, theirs
+    mine = tuple(int(x, 16) for x in m.groups()[:3])
+    return mine == (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)), ours, theirs
 
 
 def weights_count(game_id=GAME_BACKGAMMON):

@@ -95,3 +95,42 @@ print("RESULT", hashlib.sha256(out["ps"].tobytes() + out["state"].tobytes() + ou
         res[name] = ([l for l in p.stdout.decode().splitlines() if l.startswith("RESULT")][0], p.stderr.decode())
     assert "falling back to the per-layer kernels" in res["starved"][1] and "falling back" not in res["normal"][1]
     assert res["starved"][0] == res["normal"][0]          # same records, same counters: the repeated search left no trace
+
+
+def test_options_travel_through_the_abi():
+    """diee_set_option / diee_get_option (include/diee.h): what used to be environment switches.  Values round-trip, unknown keys and
+    malformed values are DIEE_ERR_ARG and change nothing, the dispatch follows (bands of the development probe), `shared_gpu` takes
+    every kernel that waits for a co-resident workgroup out of the dispatch -- and the environment is not consulted after diee_create"""
+    import os
+    import diee_amd
+    e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+    assert e.get_option("spec_eval") == "1" and e.get_option("tower_cl") == "default" and e.get_option("shared_gpu") == "0"
+    e.set_options(compact=0, deliver_stage_rows=77, tower_cl="32:1,64:2")
+    assert (e.get_option("compact"), e.get_option("deliver_stage_rows"), e.get_option("tower_cl")) == ("0", "77", "32:1,64:2")
+    for key, value in (("no_such_option", "1"), ("compact", "yes"), ("compact", "-1"), ("tower_table", "5"), ("tower_cl", "32:1,"), ("tower_table", "0:8")):
+        with pytest.raises(diee_amd.DieeError) as ei:
+            e.set_option(key, value)
+        assert ei.value.status == diee_amd.ERR_ARG, (key, value)
+    assert e.get_option("compact") == "0" and e.get_option("tower_table") == "default"
+    e.set_options(compact=1, tower_cl="default")
+    full = e.dispatch_bands(1024)
+    assert [k for _, _, k in full][:5] == ["k_tower_cl<1, 8>", "k_tower_cl<2, 8>", "k_tower_cl<4, 8>", "k_tower16p<2, 6>", "k_tower16p<4, 6>"]
+    os.environ["DIEE_SHARED_GPU"] = "1"                          # too late: the environment was read when the ctx was created
+    try:
+        assert e.dispatch_bands(1024) == full
+    finally:
+        del os.environ["DIEE_SHARED_GPU"]
+    e.set_option("shared_gpu", 1)
+    shared = [k for _, _, k in e.dispatch_bands(1024)]
+    assert not any(k.startswith(("k_tower_cl", "k_tower16p")) for k in shared) and shared[-1] == "k_tower16<4, 4, 3, 0>"
+    states = np.zeros(3, dtype=diee_amd.BG_STATE); states["pts"][:, 0] = 2; states["pts"][:, 23] = -2; states["roll"] = (3, 1); states["player"] = -1
+    r = e.alpha_mcts_parallel(states, diee_amd.MctsConfig.default(8), 1, 0, np.arange(3, dtype=np.uint32), np.zeros(3, dtype=np.uint32))
+    assert r["stats"]["tail_iterations"] == 0                   # the tail's looping kernel waits for co-resident workgroups too
+    e.set_option("shared_gpu", 0)
+    assert e.dispatch_bands(1024) == full
+    e.close()
+    t = diee_amd.Engine(0, diee_amd.GAME_TTT)
+    with pytest.raises(diee_amd.DieeError) as ei:
+        t.set_option("compact", 0)
+    assert ei.value.status == diee_amd.ERR_UNSUPPORTED
+    t.close()
