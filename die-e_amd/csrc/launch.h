@@ -89,7 +89,7 @@ void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n
 struct ExpandVariant { bool two = true, two_c = true; };    // options expand2 / expand2c
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown = false, ExpandVariant v = ExpandVariant{});   // next_it: iteration to select for afterwards, kNoNextIteration = none;
-                                                                         // pre_grown: launch_grow(it) created the children already
+                                                                         // pre_grown: the tower launch's growth workgroups created the children already (GrowReq)
 // the tail of a batch (search_types.h, Tail): launch number q of a move-step's search -- takes in the rows of tower launch q - 1, runs
 // iterations while every live game's selected leaf has its evaluation, plans the rows of tower launch q
 void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q);

@@ -1,5 +1,5 @@
 // mcts_device.h -- device code of the search shared between translation units: the tree's small helpers and grow_slot, the
-// network-independent half of an expansion, which runs as a kernel of its own (k_grow, k_fc_grow in mcts_kernels.hip) and as
+// network-independent half of an expansion, which runs on k_expand<true, 1>'s second wave (mcts_kernels.hip) and as
 // extra workgroups of the cluster-tower launch (nn_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -247,7 +247,7 @@ struct ExpandScratch {
     uint16_t code[kMaxPlays];
 };
 static_assert(sizeof(uint64_t) * 2 * kSeqCap >= sizeof(float) * 22 * 64, "the logits row fits over the dedup keys");
-// k_expand<true> (the children exist already, see k_grow): the logits row and the masked priors are all it stages
+// k_expand<true> (the children exist already, see grow_slot): the logits row and the masked priors are all it stages
 struct SettleScratch {
     float lgs[22 * 64];
     float raw[kMaxPlays];
@@ -258,7 +258,7 @@ struct SettleScratch {
 // After the expansion the same wave immediately selects this game's leaf for iteration `next_it` (kNoNext = none):
 // one MCTS kernel per network evaluation instead of two.
 constexpr uint32_t kNoNext = 0xFFFFFFFEu;
-// PRE: the children of the leaf were created by k_grow while the network ran (states, dice, parent, action code; priors open):
+// PRE: the children of the leaf were created by grow_slot while the network ran (growth workgroups of the cluster launch) (states, dice, parent, action code; priors open):
 // what is left for after the evaluation is what depends on it -- priors, the parent's link, backpropagation, the next descent.
 // TWO (with PRE): two waves per slot.  Wave 1 creates the children (grow_slot) WHILE wave 0 loads, evaluates the value head, reduces
 // the softmax and backpropagates; they meet once, wave 1 hands k and the codes over in LDS, wave 0 commits the children with their
@@ -339,7 +339,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
 #pragma unroll
         for (int q = 0; q < 22; ++q) lg[q] = 0.0f;
     }
-    // k_grow's hand-over: how many children it created for this slot (kNone: none -- nothing to expand, or no room) and
+    // grow_slot's hand-over: how many children it created for this slot (kNone: none -- nothing to expand, or no room) and
     // their action codes, four per lane (child lane + 64 q in position q)
     // the root's children, one per lane, for the first level of the descent that follows (see Level0); patched below with
     // what this kernel changes in them
@@ -641,7 +641,7 @@ __device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, 
     return v != 0xffffffffu;
 }
 
-// development builds (-DDIEE_TAIL_STAMPS): shader-clock sums per phase of k_tail, read by scripts/tail_phases.py
+// development builds (-DDIEE_TAIL_STAMPS): shader-clock sums per phase of k_tail, read by tests/tools/tail_phases.py
 #ifdef DIEE_TAIL_STAMPS
 __device__ unsigned long long g_tail_stamps[8];     // 0 take-in, 1 meeting (wait for the other games), 2 iteration body, 3 plan (virtual descents + rows), 6 iterations, 7 launches
 #define TL_STAMP(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_tail_stamps[i], tn_ - tl_prev_); tl_prev_ = __builtin_readcyclecounter(); } while (0)
@@ -1366,8 +1366,8 @@ void launch_init_roots(hipStream_t st, const Tree& T, const Slots& S, uint32_t n
 }
 void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, uint32_t it, const SearchParams& P,
                    uint32_t next_it, float c, bool pre_grown, ExpandVariant v) {
-    // v.two = false (DIEE_EXPAND2=0): one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
-    // v.two_c = false (DIEE_EXPAND2C=0): children grown by the tower launch are committed by the one wave that does everything else too
+    // v.two = false (option expand2 = 0): one wave per slot creates the children and then does the rest (k_expand<false>) instead of two waves side by side
+    // v.two_c = false (option expand2c = 0): children grown by the tower launch are committed by the one wave that does everything else too
     // (the caller reads the switches once per search: no getenv beside a kernel launch)
     if (pre_grown && v.two_c) hipLaunchKernelGGL((k_expand<true, 2>), dim3(n), dim3(128), 0, st, T, S, G, n, it, P, next_it, c);
     else if (pre_grown) hipLaunchKernelGGL((k_expand<true, 0>), dim3(n), dim3(64), 0, st, T, S, G, n, it, P, next_it, c);

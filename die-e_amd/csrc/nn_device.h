@@ -59,8 +59,7 @@ __device__ __forceinline__ float value_head(const float* __restrict__ hv_row, co
 }
 
 // ---- policy FC 768 -> 1352 (nnet.rs:80-85): one wave per 32 games x 32 outputs, operands straight from L2 (the layer is
-// ~0.2 % of the network's FLOPs).  A device function so that the search can run it inside a launch of its own that ALSO
-// grows the tree (mcts_kernels.hip, k_fc_grow); k_policy_fc is the stand-alone launch of the same code.
+// ~0.2 % of the network's FLOPs).  A device function (a tile per wave); k_policy_fc is its launch.
 typedef __attribute__((ext_vector_type(8))) __bf16 fc_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float fc_f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t fc_u32x4;

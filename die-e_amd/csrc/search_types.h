@@ -72,7 +72,7 @@ struct Slots {
     uint32_t* leaf_meta;    // [slots] Tree::meta of leaf as the selection read it (nobody else writes this game's tree)
     uint32_t* path;         // [slots][kPathCap] nodes from the root to sel (entry d = depth d): backpropagation without the parent walk
     uint8_t* path_len;      // [slots] entries of path; 0 = deeper than path_cap (or no selection yet): walk the parents
-    uint32_t* grow_k;       // [slots] children k_grow created for the slot's leaf this iteration (0xFFFFFFFF: none to create / no room)
+    uint32_t* grow_k;       // [slots] children the growth workgroups of a tower launch created for the slot's leaf this iteration (0xFFFFFFFF: none to create / no room)
     uint16_t* grow_code;    // [slots][kMaxPlays] their action codes, child lane + 64 q at [lane * 4 + q]
     uint32_t path_cap;      // depths recorded (<= kPathCap = 64; option path_cap lowers it so that tests reach the parent walk)
 };

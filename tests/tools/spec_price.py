@@ -1,4 +1,4 @@
-"""Prices speculative leaf evaluation in the tail of a self-play batch BEFORE anything is built (round-4 review, item 3).
+"""TEST INFRASTRUCTURE (it drives the CPU oracle, hence it lives under tests/): prices speculative leaf evaluation in the tail of a self-play batch BEFORE anything is built (round-4 review, item 3).
 
 At <= 32 live games one network evaluation costs the same ~95 us whether its launch carries 1 or 32 boards, and a search
 iteration is one such launch + ~8 us of tree work.  Every leaf a search selects exists (state, frozen dice) from the moment its
@@ -13,7 +13,7 @@ live-game count it reports the iterations, the launches each policy still needs,
 (launch + tree kernel = --launch-us, a skipped iteration = --skip-us).  Evaluator: the engine's network on a GPU box
 (--eval engine; the priors and values of the real random-init net shape the trees), or the oracle's hash evaluator (--eval hash).
 
-    python scripts/spec_price.py --eval engine --out profiles/r05a_spec_price.json
+    python tests/tools/spec_price.py --eval engine --out profiles/r05a_spec_price.json
 """
 import argparse
 import ctypes as C
@@ -24,7 +24,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc                                    # noqa: E402  (test infrastructure: this is a pricing tool)
 

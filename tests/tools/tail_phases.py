@@ -1,7 +1,7 @@
 """Where k_tail's time goes: shader-clock sums per phase over all its workgroups (development build -DDIEE_TAIL_STAMPS).
 
     DIEE_EXTRA_FLAGS=-DDIEE_TAIL_STAMPS DIEE_OUT=libdiee_tail_stamps.so python die-e_amd/build.py --dev
-    DIEE_LIB=die-e_amd/libdiee_tail_stamps.so python scripts/tail_phases.py [games ...]
+    DIEE_LIB=die-e_amd/libdiee_tail_stamps.so python tests/tools/tail_phases.py [games ...]
 
 One move-step's search at each number of live games; cycles per workgroup and iteration at the shader clock (~2.4 GHz unloaded)."""
 import ctypes as C
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import diee_amd
 from oracle import oracle as orc
 
