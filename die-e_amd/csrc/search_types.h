@@ -122,8 +122,8 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // earlier needs NO launch: k_tail (mcts_kernels.hip) runs the iterations of all live games in lockstep, one after the other inside
 // one launch, for as long as every selected leaf is in the ring, and plans the next launch's rows when one is not.  The search
 // itself -- selection, expansion, backpropagation, the quirks' coupling of the games of a batch -- is the same code on the same
-// numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above 64 games.
-constexpr uint32_t kTailMaxSlots = 64;    // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
+// numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above spec_max_games (96) games.
+constexpr uint32_t kTailMaxSlots = 128;   // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
 constexpr uint32_t kTailRowsMax = 128;    // rows of a tail launch at most: 32 (k_tower_cl<1, 8>, ~95 us), 64 (<2, 8>, ~125 us) or 128 (<4, 8>, ~172 us) -- one
                                           // arithmetic, so a row's bits do not depend on which of them evaluated it; the more games share a launch,
                                           // the more rows it carries (Tail::rows, search_host.cpp tail_rows_for)

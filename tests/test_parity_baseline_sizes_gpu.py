@@ -129,7 +129,7 @@ def test_self_play_1024_games_to_completion_bit_exact(eng, oracle):
     assert out["stats"]["games"] == n and out["stats"]["fragments"] == len(out["outcome"])
     assert out["stats"]["illegal_decodes"] == 0 == ref["stats"]["illegal_decodes"]
     # compaction was live while > 256 games were: fewer rows evaluated than the reference pushes -- not counting what the tail's
-    # launches (<= 64 live games) evaluate on speculation, which at iterations = 8 is more than they save
+    # launches (<= 96 live games) evaluate on speculation, which at iterations = 8 is more than they save
     assert out["stats"]["nn_rows"] - out["stats"]["tail_spec_rows"] < out["stats"]["nn_evals"]
     assert set(np.unique(out["outcome"])) <= {-1, 1}               # nobody reached the 400-round limit
 

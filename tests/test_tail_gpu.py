@@ -1,4 +1,4 @@
-"""The tail of a batch (<= 64 live games; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
+"""The tail of a batch (<= 96 live games by default, 128 at most; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
 launch for as long as every selected leaf's evaluation is at hand, and the launches in between carry speculative rows.  Nothing of
 that may show in a result: every case here holds the engine -- with the path on, with it off, and with the speculation alone off --
 to the CPU oracle's lockstep search BIT FOR BIT, and asserts that the path really ran (`tail_iterations`) and really saved launches."""
@@ -45,7 +45,8 @@ def roots_of(oracle, n, pick):
 @pytest.mark.parametrize("quirks", [1, 0])
 @pytest.mark.parametrize("n,iters,pick", [(1, 100, "mid"), (1, 100, "late"), (2, 100, "mixed"), (3, 64, "late"), (5, 100, "mixed"),
                                           (8, 100, "mid"), (16, 100, "mixed"), (16, 48, "late"), (4, 400, "mixed"),
-                                          (24, 100, "mixed"), (33, 60, "mid"), (48, 100, "late"), (64, 100, "mixed"), (3, 1600, "mixed")])
+                                          (24, 100, "mixed"), (33, 60, "mid"), (48, 100, "late"), (64, 100, "mixed"), (3, 1600, "mixed"),
+                                          (65, 40, "mixed"), (96, 60, "mid"), (128, 40, "mixed")])
 def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     states = roots_of(oracle, n, pick)
     assert len(states) == n
@@ -55,11 +56,11 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     res = {}
     for name, opts in (("tail", dict(spec_eval=1, spec_rollout_steps=24)), ("demanded rows only", dict(spec_eval=1, spec_rollout_steps=0)),
                        ("launch per iteration", dict(spec_eval=0, spec_rollout_steps=24))):
-        eng.set_options(**opts)
+        eng.set_options(spec_max_games=128, **opts)              # (the default reach is 96 games: the 128-game case asks for the kernel's whole range)
         try:
             res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 9, gids, rds, ref_quirks=bool(quirks))
         finally:
-            eng.set_options(spec_eval=1, spec_rollout_steps=24)
+            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96)
     os_ = ostats.as_dict()
     for name, r in res.items():
         assert r["probs"].tobytes() == probs.tobytes(), (name, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
@@ -72,7 +73,9 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     assert d["tail_spec_rows"] == 0 and d["tail_launches"] <= iters          # no speculation: a launch per iteration that evaluates anything, none for idle ones
     assert t["tail_launches"] <= d["tail_launches"]
     if pick != "late":
-        assert t["tail_spec_rows"] > 0 and t["tail_launches"] < (0.6 if n <= 16 else 0.85) * iters, (t["tail_launches"], iters)   # the speculation pays
+        assert t["tail_spec_rows"] > 0 and t["tail_launches"] <= (0.6 if n <= 16 else 0.85 if n <= 64 else 1.0) * iters, (t["tail_launches"], iters)   # the speculation pays
+        # (beyond 64 games a 128-row launch has fewer spare rows than games: at 128 games nearly every iteration has some game missing, and the
+        # saving left is the idle iterations and the terminal leaves)
     assert t["nn_rows"] >= t["tail_spec_rows"]
 
 
@@ -91,7 +94,7 @@ def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
         r = eng.alpha_mcts_parallel(states, gcfg, SEED, 2, gids, rds, ref_quirks=True)
         rows = eng.last_dispatch()
     finally:
-        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=64)
+        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=96)
     assert r["probs"].tobytes() == probs.tobytes()
     for key in KEYS:
         assert r["stats"][key] == ostats.as_dict()[key], key
