@@ -129,7 +129,7 @@ typedef struct {
     double   band_seconds[9];
     uint64_t band_launches[9]; /* sampled evaluations                                                                              */
     double   band_flops[9];
-    /* the tail of a batch (<= 16 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
+    /* the tail of a batch (<= spec_max_games = 96 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
      * they needed (one per iteration without it), and the rows those launches evaluated on speculation (all batches of the call,
      * reported with batch 0) */
     uint64_t tail_iterations;
@@ -174,10 +174,12 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *   tower_table           "min_boards:geometry,..."             the fused tower's table (development)
  *   compact               0 | 1   above 256 live games evaluate only the slots whose leaf needs it (default 1; 0 = every row, like the reference)
  *   spec_eval             0 | 1   speculative leaf evaluation in the free rows of the launches of a batch's tail (default 1; same results)
+ *   spec_max_games        live games (all batches of the call) up to which a move-step's search runs that way (default 96, at most 128)
+ *   spec_rows64_from, spec_rows128_from   live games from which a tail launch carries 64 / 128 rows instead of 32 (defaults 5 / 10)
  *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
  *                                 with several ranks per host: what each may retain)
  *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)
- *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps, fused_heads, cluster_heads, cluster_init, trace_steps,
+ *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps (virtual descents per game and launch, default 24), fused_heads, cluster_heads, cluster_init, trace_steps,
  *   trace_dispatch, test_starve_at                                                  development / test switches
  * Unknown key or malformed value: DIEE_ERR_ARG.  Not for a tic-tac-toe ctx (DIEE_ERR_UNSUPPORTED). */
 diee_status diee_set_option(diee_ctx*, const char* key, const char* value);
