@@ -615,7 +615,7 @@ def main(argv=None, engine_factory=None):
                       "tree_nodes_per_search": tot["children"] / max(tot["plies"], 1) + 1,
                       "tree_bytes_per_search": 56 * (tot["children"] / max(tot["plies"], 1) + 1),
                       "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64),
-                      # the tail of a batch (<= 16 live games: die-e_amd/csrc/search_types.h Tail): search iterations the looping tree kernel ran,
+                      # the tail of a batch (<= 96 live games: die-e_amd/csrc/search_types.h Tail): search iterations the looping tree kernel ran,
                       # the network launches they needed (one per iteration without it) and the rows evaluated on speculation, per batch
                       "tail": {"iterations_per_step": tot.get("tail_iterations", 0) / max(args.steps, 1) / world,
                                "launches_per_step": tot.get("tail_launches", 0) / max(args.steps, 1) / world,
