@@ -956,12 +956,17 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         const uint32_t room = L.rows - (misses < L.rows ? misses : L.rows);
         const uint32_t want0 = room / n + (slot < room % n ? 1u : 0u), want = want0 < 63u ? want0 : 63u;
         const uint32_t nu = used < kTailLdsNodes ? used : kTailLdsNodes;
-        if (want > 0 && L.rollout_steps > 0) {
+        // extra_rows: where the rows of a launch are scarce (fewer than 8 per game) a game looks for a few candidates beyond its share; they take
+        // the rows that games with nothing worth evaluating (finished-game leaves, narrow bear-off trees) leave free -- after every game has taken
+        // its share (one more meeting; the condition is the same in every workgroup)
+        const bool redistribute = L.extra_rows > 0 && L.rollout_steps > 0 && n > 1 && room > 0 && room / n < 8u;
+        const uint32_t want_x = !redistribute ? want : want + L.extra_rows < 63u ? want + L.extra_rows : 63u;
+        if (want_x > 0 && L.rollout_steps > 0) {
             for (uint32_t i = lane; i < nu; i += 64) { D.vvis[i] = D.t.vis[i]; D.vval[i] = D.t.val[i]; }
             __syncthreads();
             const uint32_t demanded = hit ? kNone : leaf;
             uint32_t fruitless = 0;
-            for (uint32_t step = 0; step < L.rollout_steps && ncand < want && fruitless < 8; ++step) {
+            for (uint32_t step = 0; step < L.rollout_steps && ncand < want_x && fruitless < 8; ++step) {
                 uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
                 for (;;) {
                     mt = X.meta(node);
@@ -994,7 +999,8 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                 __syncthreads();
             }
         }
-        mine_rows = (hit ? 0u : 1u) + ncand;
+        const uint32_t share = ncand < want ? ncand : want;
+        mine_rows = (hit ? 0u : 1u) + share;
         uint32_t start = 0;
         if (lane == 0 && mine_rows) start = atomicAdd(&L.n_rows[A.q], mine_rows);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
@@ -1004,8 +1010,24 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
             store_state(&L.rows_state[r], (!hit && lane == 0) ? lst : load_state(&T.state[base + node]));
             L.rows_node[r] = (slot << 24) | node;
         }
-        cn[SC_NN_ROWS] += mine_rows;
-        if (lane == 0 && ncand) atomicAdd(&L.state[3], ncand);
+        uint32_t extra = 0;
+        if (redistribute) {
+            uint32_t unused_;
+            const bool met = tail_meet(L.bar2 + A.q, n, true, lane, S.overflow, unused_);       // every game's share is taken
+            extra = met ? ncand - share : 0u;
+            uint32_t start2 = 0;
+            if (lane == 0 && extra) start2 = atomicAdd(&L.n_rows[A.q], extra);                  // (may run past L.rows: readers clamp)
+            start2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start2);
+            extra = start2 >= L.rows ? 0u : extra < L.rows - start2 ? extra : L.rows - start2;
+            if ((uint32_t)lane < extra) {
+                const uint32_t node = D.cand[share + (uint32_t)lane];
+                const uint32_t r = A.q * L.rows + start2 + (uint32_t)lane;
+                store_state(&L.rows_state[r], load_state(&T.state[base + node]));
+                L.rows_node[r] = (slot << 24) | node;
+            }
+        }
+        cn[SC_NN_ROWS] += mine_rows + extra;
+        if (lane == 0 && share + extra) atomicAdd(&L.state[3], share + extra);
     }
     if (lane == 0) store_counters(S, slot, cn);
     TL_STAMP(3);

@@ -267,13 +267,14 @@ Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
         B.tl_crow.ensure((size_t)kTailMaxSlots * nc); B.tl_cval.ensure((size_t)kTailMaxSlots * nc);
         B.tl_rows_state.ensure((size_t)L * kTailRowsMax); B.tl_rows_node.ensure((size_t)L * kTailRowsMax);
         B.tl_logits.ensure((size_t)L * kTailRowsMax * 1352); B.tl_hv.ensure((size_t)L * kTailRowsMax * 72);
-        B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8);
+        B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8 + (size_t)L);
         B.tl_launches = L; B.tl_node_cap = nc;
     }
     if (!B.tl_host) { HIPCHK(hipHostMalloc((void**)&B.tl_host, sizeof(uint32_t) * 4)); memset(B.tl_host, 0, sizeof(uint32_t) * 4); }
     uint32_t* w = B.tl_words.p;
     return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + B.tl_launches, w + B.tl_launches + 4,
-                B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n)};
+                w + B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8, B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n),
+                e.opt.spec_extra_rows};
 }
 
 // The iterations of one move-step's search for n <= kTailMaxSlots (option spec_max_games) live games, behind the root expansion (k_expand has selected every
@@ -287,7 +288,7 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     hipStream_t st = e.stream;
     // crow of the slots in use (the trees are rebuilt every move-step), the row counts, state words and meeting words
     HIPCHK(hipMemsetAsync(L.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
-    HIPCHK(hipMemsetAsync(B.tl_words.p, 0, sizeof(uint32_t) * ((size_t)B.tl_launches + 4 + 2 * (size_t)L.launches + 8), st));
+    HIPCHK(hipMemsetAsync(B.tl_words.p, 0, sizeof(uint32_t) * ((size_t)B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8 + (size_t)L.launches), st));
     B.tl_host[1] = 0; B.tl_host[2] = 0xFFFFFFFFu;
     launch_tail(st, T, S, G, n, P, cfg.c, L, 0);
     uint32_t q = 0, sent = 0;

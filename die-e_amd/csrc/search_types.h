@@ -138,11 +138,13 @@ struct Tail {
     uint32_t* n_rows;       // [launches] rows of launch q (0: nothing to evaluate, the launch returns at once)
     uint32_t* state;        // [0] next iteration, [1] done, [2] launches that carried rows, [3] rows evaluated on speculation
     uint32_t* bar;          // [2 * launches + 8] one word per meeting of the games' workgroups (zeroed per move-step)
+    uint32_t* bar2;         // [launches] the meeting inside the plan of launch q (extra_rows: shares taken before the free rows left over are)
     uint32_t* host;         // pinned host words: [0] next iteration, [1] done, [2] index of the last k_tail launch that finished
     uint32_t launches;      // iterations + 1
     uint32_t iterations;
     uint32_t rollout_steps; // virtual descents per game and launch at most
     uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128)
+    uint32_t extra_rows;    // candidates a game may find beyond its share of a full launch's rows: they take what other games left free (0: off)
 };
 
 struct SearchParams {

@@ -176,6 +176,7 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *   spec_eval             0 | 1   speculative leaf evaluation in the free rows of the launches of a batch's tail (default 1; same results)
  *   spec_max_games        live games (all batches of the call) up to which a move-step's search runs that way (default 96, at most 128)
  *   spec_rows64_from, spec_rows128_from   live games from which a tail launch carries 64 / 128 rows instead of 32 (defaults 5 / 10)
+ *   spec_extra_rows       candidates a game may find beyond its share of a tail launch whose rows are scarce: they take what other games leave free (default 2)
  *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
  *                                 with several ranks per host: what each may retain)
  *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)

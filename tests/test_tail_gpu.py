@@ -80,10 +80,12 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
 
 
 @pytest.mark.parametrize("opts", [dict(spec_rows64_from=1, spec_rows128_from=2), dict(spec_rows64_from=65, spec_rows128_from=65),
-                                  dict(spec_rows64_from=3, spec_rows128_from=65), dict(spec_max_games=7)])
+                                  dict(spec_rows64_from=3, spec_rows128_from=65), dict(spec_max_games=7),
+                                  dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=0), dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=9)])
 def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
     """a tail launch carries 32, 64 or 128 rows depending on the live games (k_tower_cl<1, 8> / <2, 8> / <4, 8>: one arithmetic per row):
-    whatever the thresholds say, and wherever the path hands over to the launch-per-iteration search, the same bits"""
+    whatever the thresholds say, wherever the path hands over to the launch-per-iteration search, and whether or not the games take the
+    rows their neighbours leave free (spec_extra_rows: 9 games on 32 rows, scarce, so that the second round of claims runs), the same bits"""
     n, iters = 9, 48
     states = roots_of(oracle, n, "mixed")
     ocfg, gcfg = cfgs(oracle, iters)
@@ -94,7 +96,7 @@ def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
         r = eng.alpha_mcts_parallel(states, gcfg, SEED, 2, gids, rds, ref_quirks=True)
         rows = eng.last_dispatch()
     finally:
-        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=96)
+        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=96, spec_extra_rows=2)
     assert r["probs"].tobytes() == probs.tobytes()
     for key in KEYS:
         assert r["stats"][key] == ostats.as_dict()[key], key
