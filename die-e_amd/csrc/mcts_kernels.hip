@@ -752,7 +752,14 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         D.t.crow[i] = crow_g[i]; D.t.cval[i] = cval_g[i];
     }
     __syncthreads();
+    // children the plan of launch q - 1 created ahead for this game's demanded leaf (child_rows) sit at [used, ahead_hi): evaluated before their
+    // parent is expanded -- which the first iteration below does, creating exactly these nodes; it must not clear their rows then
+    uint32_t ahead_hi = used;
     if (A.q > 0) {
+        if (L.child_rows > 0) {
+            for (uint32_t i = used + (uint32_t)lane; i < used + (uint32_t)kMaxPlays && i < kTailLdsNodes; i += 64) { D.t.crow[i] = 0; D.t.cval[i] = 0.0f; }
+            __syncthreads();
+        }
         const uint32_t pq = A.q - 1, nr = L.n_rows[pq] < L.rows ? L.n_rows[pq] : L.rows;
         for (uint32_t r = lane; r < nr; r += 64) {
             const uint32_t rn = L.rows_node[pq * L.rows + r];
@@ -764,8 +771,10 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                 const float cv = tanhf(dot + S.wv[72]);
                 cval_g[node] = cv; crow_g[node] = pq * L.rows + r + 1u;
                 if (node < kTailLdsNodes) { D.t.cval[node] = cv; D.t.crow[node] = pq * L.rows + r + 1u; }
+                if (node >= ahead_hi) ahead_hi = node + 1u;
             }
         }
+        ahead_hi = (uint32_t)wave_allmax_i32((int)ahead_hi);
         __syncthreads();
     }
     TL_STAMP(0);
@@ -847,7 +856,8 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                         T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = prj;
                         T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = cm;
                         if (cl < kTailLdsNodes) {
-                            D.t.vis[cl] = 0.0f; D.t.val[cl] = 0.0f; D.t.pri[cl] = prj; D.t.meta[cl] = cm; D.t.fc[cl] = 0; D.t.crow[cl] = 0; D.t.cval[cl] = 0.0f;
+                            D.t.vis[cl] = 0.0f; D.t.val[cl] = 0.0f; D.t.pri[cl] = prj; D.t.meta[cl] = cm; D.t.fc[cl] = 0;
+                            if (cl >= ahead_hi) { D.t.crow[cl] = 0; D.t.cval[cl] = 0.0f; }       // (below: evaluated ahead, or cleared at the take-in)
                         }
                     }
                     const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
@@ -958,8 +968,9 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         const uint32_t nu = used < kTailLdsNodes ? used : kTailLdsNodes;
         // extra_rows: where the rows of a launch are scarce (fewer than 8 per game) a game looks for a few candidates beyond its share; they take
         // the rows that games with nothing worth evaluating (finished-game leaves, narrow bear-off trees) leave free -- after every game has taken
-        // its share (one more meeting; the condition is the same in every workgroup)
+        // its share (one more meeting; the conditions are the same in every workgroup)
         const bool redistribute = L.extra_rows > 0 && L.rollout_steps > 0 && n > 1 && room > 0 && room / n < 8u;
+        const bool second_round = redistribute || L.child_rows > 0;
         const uint32_t want_x = !redistribute ? want : want + L.extra_rows < 63u ? want + L.extra_rows : 63u;
         if (want_x > 0 && L.rollout_steps > 0) {
             for (uint32_t i = lane; i < nu; i += 64) { D.vvis[i] = D.t.vis[i]; D.vval[i] = D.t.val[i]; }
@@ -999,31 +1010,52 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                 __syncthreads();
             }
         }
-        const uint32_t share = ncand < want ? ncand : want;
-        mine_rows = (hit ? 0u : 1u) + share;
+        // child_rows: a game whose leaf waits for its evaluation will expand it in iteration `it`, the first of the next launch -- so the children's
+        // dice (keyed by the expanding iteration) are known NOW, and the children can ride in the same launch as their parent: a search that
+        // deepens (select the node just expanded's best child, expand it, select ITS best child ...) otherwise misses at every iteration.  Up to
+        // child_rows of them, in play order (the priors that rank them are in the evaluation the leaf is waiting for), from the rows the shares leave free.
+        uint32_t nchild = 0;
+        if (L.child_rows > 0 && !hit && !(leaf_meta & kDrained)) {
+            int k = bg_legal_plays_wave(lst, &D.ws, lane, S.overflow);
+            if (k > kMaxPlays || used + (uint32_t)k > T.node_cap) k = 0;                              // (the expansion itself will report it)
+            nchild = (uint32_t)k < L.child_rows ? (uint32_t)k : L.child_rows;
+            __syncthreads();
+        }
+        const uint32_t share = ncand < want ? ncand : want, dem = hit ? 0u : 1u;
+        mine_rows = dem + share;
         uint32_t start = 0;
         if (lane == 0 && mine_rows) start = atomicAdd(&L.n_rows[A.q], mine_rows);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         if ((uint32_t)lane < mine_rows && start + (uint32_t)lane < L.rows) {
-            const uint32_t node = (!hit && lane == 0) ? leaf : D.cand[lane - (hit ? 0 : 1)];
+            const uint32_t node = (dem && lane == 0) ? leaf : D.cand[(uint32_t)lane - dem];
             const uint32_t r = A.q * L.rows + start + (uint32_t)lane;
-            store_state(&L.rows_state[r], (!hit && lane == 0) ? lst : load_state(&T.state[base + node]));
+            store_state(&L.rows_state[r], (dem && lane == 0) ? lst : load_state(&T.state[base + node]));
             L.rows_node[r] = (slot << 24) | node;
         }
         uint32_t extra = 0;
-        if (redistribute) {
+        if (second_round) {
             uint32_t unused_;
             const bool met = tail_meet(L.bar2 + A.q, n, true, lane, S.overflow, unused_);       // every game's share is taken
-            extra = met ? ncand - share : 0u;
+            const uint32_t more = redistribute ? ncand - share : 0u;
+            extra = met ? nchild + more : 0u;
             uint32_t start2 = 0;
             if (lane == 0 && extra) start2 = atomicAdd(&L.n_rows[A.q], extra);                  // (may run past L.rows: readers clamp)
             start2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start2);
             extra = start2 >= L.rows ? 0u : extra < L.rows - start2 ? extra : L.rows - start2;
-            if ((uint32_t)lane < extra) {
-                const uint32_t node = D.cand[share + (uint32_t)lane];
-                const uint32_t r = A.q * L.rows + start2 + (uint32_t)lane;
-                store_state(&L.rows_state[r], load_state(&T.state[base + node]));
-                L.rows_node[r] = (slot << 24) | node;
+            for (uint32_t j = (uint32_t)lane; j < extra; j += 64) {
+                const uint32_t r = A.q * L.rows + start2 + j;
+                if (j < nchild) {                                                               // the demanded leaf's children, as iteration `it` will create them
+                    BgState cs = lst;
+                    int d0, d1;
+                    draw_dice(seed, gid, rnd, it + 1u, j, d0, d1);
+                    bg_apply_dev(cs, D.ws.play[j], d0, d1);
+                    store_state(&L.rows_state[r], cs);
+                    L.rows_node[r] = (slot << 24) | (used + j);
+                } else {
+                    const uint32_t node = D.cand[share + (j - nchild)];
+                    store_state(&L.rows_state[r], load_state(&T.state[base + node]));
+                    L.rows_node[r] = (slot << 24) | node;
+                }
             }
         }
         cn[SC_NN_ROWS] += mine_rows + extra;

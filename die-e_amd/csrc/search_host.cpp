@@ -274,7 +274,7 @@ Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     uint32_t* w = B.tl_words.p;
     return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + B.tl_launches, w + B.tl_launches + 4,
                 w + B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8, B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n),
-                e.opt.spec_extra_rows};
+                e.opt.spec_child_rows, e.opt.spec_extra_rows};
 }
 
 // The iterations of one move-step's search for n <= kTailMaxSlots (option spec_max_games) live games, behind the root expansion (k_expand has selected every

@@ -144,6 +144,7 @@ struct Tail {
     uint32_t iterations;
     uint32_t rollout_steps; // virtual descents per game and launch at most
     uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128)
+    uint32_t child_rows;    // children of a demanded leaf (created ahead: their dice are keyed by the iteration that will expand it) that ride in its launch at most (0: off)
     uint32_t extra_rows;    // candidates a game may find beyond its share of a full launch's rows: they take what other games left free (0: off)
 };
 

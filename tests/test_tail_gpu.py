@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SEED = 0xD1EE0001
+CHILD_ROWS = 16          # the default of option spec_child_rows
 KEYS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
 
 
@@ -54,13 +55,13 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     gids = np.arange(40, 40 + n, dtype=np.uint32); rds = (np.arange(n, dtype=np.uint32) * 3) % 11
     roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 9, gids, rds, quirks)
     res = {}
-    for name, opts in (("tail", dict(spec_eval=1, spec_rollout_steps=24)), ("demanded rows only", dict(spec_eval=1, spec_rollout_steps=0)),
+    for name, opts in (("tail", dict(spec_eval=1, spec_rollout_steps=24)), ("demanded rows only", dict(spec_eval=1, spec_rollout_steps=0, spec_child_rows=0)),
                        ("launch per iteration", dict(spec_eval=0, spec_rollout_steps=24))):
         eng.set_options(spec_max_games=128, **opts)              # (the default reach is 96 games: the 128-game case asks for the kernel's whole range)
         try:
             res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 9, gids, rds, ref_quirks=bool(quirks))
         finally:
-            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96)
+            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96, spec_child_rows=CHILD_ROWS)
     os_ = ostats.as_dict()
     for name, r in res.items():
         assert r["probs"].tobytes() == probs.tobytes(), (name, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
@@ -81,11 +82,14 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
 
 @pytest.mark.parametrize("opts", [dict(spec_rows64_from=1, spec_rows128_from=2), dict(spec_rows64_from=65, spec_rows128_from=65),
                                   dict(spec_rows64_from=3, spec_rows128_from=65), dict(spec_max_games=7),
-                                  dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=0), dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=9)])
+                                  dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=0), dict(spec_rows64_from=65, spec_rows128_from=65, spec_extra_rows=9),
+                                  dict(spec_rows64_from=65, spec_rows128_from=65, spec_child_rows=0), dict(spec_rows64_from=65, spec_rows128_from=65, spec_child_rows=3),
+                                  dict(spec_rows64_from=65, spec_rows128_from=65, spec_child_rows=200, spec_extra_rows=0)])
 def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
     """a tail launch carries 32, 64 or 128 rows depending on the live games (k_tower_cl<1, 8> / <2, 8> / <4, 8>: one arithmetic per row):
     whatever the thresholds say, wherever the path hands over to the launch-per-iteration search, and whether or not the games take the
-    rows their neighbours leave free (spec_extra_rows: 9 games on 32 rows, scarce, so that the second round of claims runs), the same bits"""
+    rows their neighbours leave free (spec_extra_rows: 9 games on 32 rows, scarce, so that the second round of claims runs) or send the
+    children of a demanded leaf along with it (spec_child_rows), the same bits"""
     n, iters = 9, 48
     states = roots_of(oracle, n, "mixed")
     ocfg, gcfg = cfgs(oracle, iters)
@@ -96,7 +100,7 @@ def test_tail_rows_per_launch_change_nothing(eng, oracle, opts):
         r = eng.alpha_mcts_parallel(states, gcfg, SEED, 2, gids, rds, ref_quirks=True)
         rows = eng.last_dispatch()
     finally:
-        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=96, spec_extra_rows=2)
+        eng.set_options(spec_rows64_from=5, spec_rows128_from=10, spec_max_games=96, spec_extra_rows=2, spec_child_rows=CHILD_ROWS)
     assert r["probs"].tobytes() == probs.tobytes()
     for key in KEYS:
         assert r["stats"][key] == ostats.as_dict()[key], key
