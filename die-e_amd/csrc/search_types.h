@@ -123,6 +123,9 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // one launch, for as long as every selected leaf is in the ring, and plans the next launch's rows when one is not.  The search
 // itself -- selection, expansion, backpropagation, the quirks' coupling of the games of a batch -- is the same code on the same
 // numbers in the same order (expand_body): results are bit-identical to the launch-per-iteration path, which remains above spec_max_games (96) games.
+// What rides in a launch beside the demanded leaves: every game's share of candidates (virtual descents), the candidates beyond the shares
+// where rows are scarce (extra_rows: they take what other games leave free), and the children of a demanded leaf (child_rows: the one
+// parent whose expanding iteration -- the key of its children's dice -- is known before it is expanded).
 constexpr uint32_t kTailMaxSlots = 128;   // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
 constexpr uint32_t kTailRowsMax = 128;    // rows of a tail launch at most: 32 (k_tower_cl<1, 8>, ~95 us), 64 (<2, 8>, ~125 us) or 128 (<4, 8>, ~172 us) -- one
                                           // arithmetic, so a row's bits do not depend on which of them evaluated it; the more games share a launch,
