@@ -76,6 +76,9 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
                           const uint32_t* row_slot, const uint32_t* n_rows, uint16_t* pair_ex = nullptr, uint32_t* err = nullptr);
 // pair tower (k_tower16p): the fused tower with 4 boards per PAIR of workgroups, 257 ... 512 boards; `ex` = tower_pair_exchange_bytes()
 // of zeroed device memory, `err` gets bit 2 set if a hand-over timed out.  false = too many boards.
+// the 4-board pair tower over the first *n_rows (counted on the device, <= G) of G dense rows: a tail launch at 129 ... 256 live games
+void launch_tower_pair_counted(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16, const float* binit,
+                               const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err, const uint32_t* n_rows);
 bool launch_tower_pair(hipStream_t st, int boards_per_pair /* 4 or 2 */, const void* wt16, const float* bias, int G, const void* states, const void* winit16,
                        const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err);
 bool tower_pair_device_ok(int device);     // 8 XCDs x >= 32 CUs: the pair's co-placement (blockIdx & 7) and co-residency (<= 256 workgroups) hold

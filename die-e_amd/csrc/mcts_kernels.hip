@@ -1039,7 +1039,11 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
             const uint32_t more = redistribute ? ncand - share : 0u;
             extra = met ? nchild + more : 0u;
             uint32_t start2 = 0;
-            if (lane == 0 && extra) start2 = atomicAdd(&L.n_rows[A.q], extra);                  // (may run past L.rows: readers clamp)
+            if (lane == 0 && extra) {
+                start2 = atomicAdd(&L.n_rows[A.q], extra);
+                const uint32_t fit = start2 >= L.rows ? 0u : extra < L.rows - start2 ? extra : L.rows - start2;
+                if (fit < extra) atomicSub(&L.n_rows[A.q], extra - fit);                        // the count ends at the rows in use (<= L.rows): once it has
+            }                                                                                   // reached L.rows it never falls below, so no two claims overlap
             start2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start2);
             extra = start2 >= L.rows ? 0u : extra < L.rows - start2 ? extra : L.rows - start2;
             for (uint32_t j = (uint32_t)lane; j < extra; j += 64) {

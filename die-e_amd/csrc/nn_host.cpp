@@ -517,6 +517,11 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
 bool nn_tail_available(Engine& e, int G_upper) {
     if (!e.net || !e.net->loaded) return false;
     const NetWeights& W = *e.net;
+    // 512 rows: the tail of 129 ... 256 live games.  Their plain evaluations are of the fused 16x16x32 family (pair tower <2>, or its
+    // fallback geometry), and so is the 4-board pair tower that takes a tail launch's rows: one arithmetic per row again
+    if (G_upper == kTailFusedRows)
+        return W.pair_tower && W.fused_heads && W.cluster_init && tower_pair_max_boards(4) >= kTailFusedRows && W.tower_geometry_for(129) >= 2 &&
+               W.tower_geometry_for(256) >= 2;
     if (!W.cluster_init || !W.cluster_heads || W.invariant) return false;
     // (1, 2 and 4 boards per cluster split K over 8 waves: one arithmetic; 8 boards per cluster splits it over 4: another)
     for (const auto& r : W.cluster_table) if (G_upper <= r.max_games) return r.boards_per_group == 1 || r.boards_per_group == 2 || r.boards_per_group == 4;
@@ -535,11 +540,25 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
         rows_log = W.rows_log.p + seq;
         ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, e.stream));
     }
-    const struct GrowReq* saved = W.grow_req; W.grow_req = nullptr;      // (k_tail grows the tree itself)
-    const bool ok = cluster_tower(e, W, G_upper, states_dev, W.actX.p, W.actH.p, hv_out, logits_out, n_rows_dev, rows_log);
-    W.grow_req = saved;
+    bool ok;
     W.last_dispatch.clear();
-    if (ok) { W.cluster_used = true; W.last_dispatch.push_back({3, cluster_boards_for(W, G_upper), G_upper}); }
+    if (G_upper == kTailFusedRows) {
+        uint16_t* pex = pair_exchange(e);
+        ok = pex != nullptr;
+        if (ok) {
+            launch_tower_pair_counted(e.stream, W.wtower16.p, W.btower.p, G_upper, states_dev, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
+                                      W.hp.p, hv_out, pex, e.flags_dev.p, n_rows_dev);
+            fc_launch(e, W.hp.p, logits_out, G_upper, n_rows_dev);
+            if (rows_log) HIPCHK(hipMemcpyAsync(rows_log, n_rows_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, e.stream));
+            W.cluster_used = true;                                       // (its hand-overs report through the same flag bit)
+            W.last_dispatch.push_back({2, 4, G_upper});
+        }
+    } else {
+        const struct GrowReq* saved = W.grow_req; W.grow_req = nullptr;      // (k_tail grows the tree itself)
+        ok = cluster_tower(e, W, G_upper, states_dev, W.actX.p, W.actH.p, hv_out, logits_out, n_rows_dev, rows_log);
+        W.grow_req = saved;
+        if (ok) { W.cluster_used = true; W.last_dispatch.push_back({3, cluster_boards_for(W, G_upper), G_upper}); }
+    }
     if (sample) {
         if (ok) {
             HIPCHK(hipEventRecord(ev1, e.stream));

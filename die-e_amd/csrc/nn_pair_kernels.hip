@@ -431,6 +431,11 @@ void launch_tower_pair_rows(hipStream_t st, const void* wt16, const float* bias,
                             const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err, const RowMap& rm) {
     tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err, rm);
 }
+void launch_tower_pair_counted(hipStream_t st, const void* wt16, const float* bias, int G, const void* states, const void* winit16, const float* binit,
+                               const void* whead16, const float* bhead, uint16_t* hp, float* hv, uint16_t* ex, uint32_t* err, const uint32_t* n_rows) {
+    // (RowMap mode 3 without a main launch and without a row map: rows [0, *n_rows) are the boards, G <= kRemSplit bounds them)
+    tower16p_launch<4, DIEE_PAIR_PF>(st, wt16, bias, G, states, winit16, binit, whead16, bhead, hp, hv, ex, err, RowMap{nullptr, n_rows, 3, 0});
+}
 bool tower_pair_device_ok(int device) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return false;

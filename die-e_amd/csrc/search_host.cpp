@@ -41,7 +41,7 @@ struct SearchBufs {
     DevBuf<float> tl_cval, tl_logits, tl_hv;
     DevBuf<BgState> tl_rows_state;
     uint32_t* tl_host = nullptr;                               // pinned, [4]
-    uint32_t tl_launches = 0, tl_node_cap = 0;
+    uint32_t tl_launches = 0, tl_node_cap = 0, tl_rows_cap = 0;
     uint32_t tl_prev_need = 0;                                 // tower launches the previous move-step's search needed (sizes the first chunk)
     uint64_t tl_iterations = 0, tl_launched = 0, tl_with_rows = 0, tl_spec_rows = 0, tl_syncs = 0;      // this call's totals
     // batches ("segments") in flight
@@ -253,22 +253,26 @@ void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint3
 // rows of a tail launch by live games: a launch of 32 / 64 / 128 boards costs ~95 / 125 / 172 us, and a search needs about
 // 91 / (1 + s) launches when every game gets s speculative rows per launch (s saturates near 8: the rows come from nodes that exist)
 uint32_t tail_rows_for(const Engine& e, uint32_t n) {
+    if (n > kTailRowsMax) return (uint32_t)kTailFusedRows;          // 129 ... 256 live games: the fused family
     return n >= e.opt.spec_rows128_from ? 128u : n >= e.opt.spec_rows64_from ? 64u : 32u;
 }
 bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
-    return e.opt.spec_eval != 0 && n >= 1 && n <= std::min<uint32_t>(e.opt.spec_max_games, kTailMaxSlots) && cfg.iterations >= 1 &&
-           nn_tail_available(e, (int)tail_rows_for(e, n));
+    if (e.opt.spec_eval == 0 || n < 1 || cfg.iterations < 1) return false;
+    const bool cluster_family = n <= std::min<uint32_t>(e.opt.spec_max_games, kTailRowsMax);
+    const bool fused_family = n > kTailRowsMax && n <= std::min<uint32_t>(e.opt.spec_fused_games, kTailMaxSlots);
+    return (cluster_family || fused_family) && nn_tail_available(e, (int)tail_rows_for(e, n));
 }
 
 Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     const uint32_t launches = cfg.iterations + 1;
-    if (launches > B.tl_launches || B.node_cap > B.tl_node_cap) {
-        const uint32_t L = std::max(launches, B.tl_launches), nc = std::max(B.node_cap, B.tl_node_cap);
+    const uint32_t rows_now = tail_rows_for(e, n) > kTailRowsMax ? (uint32_t)kTailFusedRows : kTailRowsMax;
+    if (launches > B.tl_launches || B.node_cap > B.tl_node_cap || rows_now > B.tl_rows_cap) {
+        const uint32_t L = std::max(launches, B.tl_launches), nc = std::max(B.node_cap, B.tl_node_cap), R = std::max(rows_now, B.tl_rows_cap);
         B.tl_crow.ensure((size_t)kTailMaxSlots * nc); B.tl_cval.ensure((size_t)kTailMaxSlots * nc);
-        B.tl_rows_state.ensure((size_t)L * kTailRowsMax); B.tl_rows_node.ensure((size_t)L * kTailRowsMax);
-        B.tl_logits.ensure((size_t)L * kTailRowsMax * 1352); B.tl_hv.ensure((size_t)L * kTailRowsMax * 72);
+        B.tl_rows_state.ensure((size_t)L * R); B.tl_rows_node.ensure((size_t)L * R);
+        B.tl_logits.ensure((size_t)L * R * 1352); B.tl_hv.ensure((size_t)L * R * 72);
         B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8 + (size_t)L);
-        B.tl_launches = L; B.tl_node_cap = nc;
+        B.tl_launches = L; B.tl_node_cap = nc; B.tl_rows_cap = R;
     }
     if (!B.tl_host) { HIPCHK(hipHostMalloc((void**)&B.tl_host, sizeof(uint32_t) * 4)); memset(B.tl_host, 0, sizeof(uint32_t) * 4); }
     uint32_t* w = B.tl_words.p;

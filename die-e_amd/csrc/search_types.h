@@ -126,7 +126,8 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // What rides in a launch beside the demanded leaves: every game's share of candidates (virtual descents), the candidates beyond the shares
 // where rows are scarce (extra_rows: they take what other games leave free), and the children of a demanded leaf (child_rows: the one
 // parent whose expanding iteration -- the key of its children's dice -- is known before it is expanded).
-constexpr uint32_t kTailMaxSlots = 128;   // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
+constexpr uint32_t kTailMaxSlots = 256;   // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
+constexpr int kTailFusedRows = 512;      // rows of a tail launch at 129 ... 256 live games: the 4-board pair tower + k_policy_fc (the fused family, like those games' plain evaluations)
 constexpr uint32_t kTailRowsMax = 128;    // rows of a tail launch at most: 32 (k_tower_cl<1, 8>, ~95 us), 64 (<2, 8>, ~125 us) or 128 (<4, 8>, ~172 us) -- one
                                           // arithmetic, so a row's bits do not depend on which of them evaluated it; the more games share a launch,
                                           // the more rows it carries (Tail::rows, search_host.cpp tail_rows_for)

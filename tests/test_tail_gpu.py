@@ -47,7 +47,8 @@ def roots_of(oracle, n, pick):
 @pytest.mark.parametrize("n,iters,pick", [(1, 100, "mid"), (1, 100, "late"), (2, 100, "mixed"), (3, 64, "late"), (5, 100, "mixed"),
                                           (8, 100, "mid"), (16, 100, "mixed"), (16, 48, "late"), (4, 400, "mixed"),
                                           (24, 100, "mixed"), (33, 60, "mid"), (48, 100, "late"), (64, 100, "mixed"), (3, 1600, "mixed"),
-                                          (65, 40, "mixed"), (96, 60, "mid"), (128, 40, "mixed")])
+                                          (65, 40, "mixed"), (96, 60, "mid"), (128, 40, "mixed"),
+                                          (129, 30, "mid"), (200, 40, "mixed"), (256, 30, "mid")])       # (above 128: 512-row launches of the fused family)
 def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     states = roots_of(oracle, n, pick)
     assert len(states) == n
