@@ -61,6 +61,7 @@ struct Options {
     int spec_eval = 1;                      // the tail of a batch (<= spec_max_games live games): iterations in one launch while the leaves' evaluations are at
                                             // hand, speculative rows in the launches in between (search_types.h, Tail); 0: one launch per iteration
     uint32_t spec_rollout_steps = 24;       // virtual descents per game and launch that look for those rows (0: demanded rows only)
+    uint32_t spec_fused_from = 129;         // live games from which a tail launch is one of the fused family (where tower_table sends the plain evaluations of so many boards)
     uint32_t spec_fused_games = 256;        // 129 ... this many live games search in tail mode too, on 512-row launches of the fused family (<= 256; 0: off)
     uint32_t spec_child_rows = 16;          // children of a demanded leaf that are evaluated in the same tail launch as the leaf at most (created ahead; 0: off)
     uint32_t spec_extra_rows = 2;           // candidates a game may find beyond its share of a full tail launch: they take the rows other games left free

@@ -514,18 +514,21 @@ bool nn_forward(Engine& e, const void* states_dev, int G, float* policy_dev, flo
 // G_upper states whose number k_tail wrote to *n_rows_dev on the device, outputs straight into the caller's ring rows.  The kernel is
 // the one every batch of at most 32 boards runs (k_tower_cl<1, 8>: the same bits per row whatever shares the launch).  false = this
 // ctx cannot (no such cluster rule, or the grid would not be co-resident): the caller searches launch by launch instead.
-bool nn_tail_available(Engine& e, int G_upper) {
+bool nn_tail_available(Engine& e, int G_upper, int n) {
     if (!e.net || !e.net->loaded) return false;
     const NetWeights& W = *e.net;
-    // 512 rows: the tail of 129 ... 256 live games.  Their plain evaluations are of the fused 16x16x32 family (pair tower <2>, or its
-    // fallback geometry), and so is the 4-board pair tower that takes a tail launch's rows: one arithmetic per row again
+    // the rows of a tail launch must be evaluated with the arithmetic of a plain evaluation of the n live games (what the oracle's evaluator runs)
+    // 512 rows: the plain evaluations of these n games are of the fused 16x16x32 family (pair tower <2>, or its fallback geometry), and so is
+    // the 4-board pair tower that takes a tail launch's rows: one arithmetic per row again
     if (G_upper == kTailFusedRows)
-        return W.pair_tower && W.fused_heads && W.cluster_init && tower_pair_max_boards(4) >= kTailFusedRows && W.tower_geometry_for(129) >= 2 &&
-               W.tower_geometry_for(256) >= 2;
-    if (!W.cluster_init || !W.cluster_heads || W.invariant) return false;
+        return W.pair_tower && W.fused_heads && W.cluster_init && tower_pair_max_boards(4) >= kTailFusedRows && W.tower_geometry_for(n) >= 2;
+    if (!W.cluster_init || !W.cluster_heads || W.invariant || W.tower_geometry_for(n) >= 0) return false;
     // (1, 2 and 4 boards per cluster split K over 8 waves: one arithmetic; 8 boards per cluster splits it over 4: another)
-    for (const auto& r : W.cluster_table) if (G_upper <= r.max_games) return r.boards_per_group == 1 || r.boards_per_group == 2 || r.boards_per_group == 4;
-    return false;
+    auto split8 = [&](int G) {
+        for (const auto& r : W.cluster_table) if (G <= r.max_games) return r.boards_per_group == 1 || r.boards_per_group == 2 || r.boards_per_group == 4;
+        return false;
+    };
+    return split8(G_upper) && split8(n);
 }
 bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band) {
     NetWeights& W = *e.net;

@@ -112,7 +112,7 @@ NetHeads nn_heads(Engine& e, int G);     // valid until a larger batch is reserv
 const char* nn_kernel_name(int family, int geometry);
 struct DispatchBand { int boards_min, boards_max, family, geometry; };
 std::vector<DispatchBand> nn_dispatch_bands(Engine& e, int upto);
-bool nn_tail_available(Engine& e, int G_upper);
+bool nn_tail_available(Engine& e, int G_upper, int n);
 bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band);
 bool nn_cluster_used(Engine& e);
 void nn_disable_cluster(Engine& e);

@@ -253,14 +253,15 @@ void draw_noise(SearchBufs& B, int buf, const std::vector<diee_batch>& bt, uint3
 // rows of a tail launch by live games: a launch of 32 / 64 / 128 boards costs ~95 / 125 / 172 us, and a search needs about
 // 91 / (1 + s) launches when every game gets s speculative rows per launch (s saturates near 8: the rows come from nodes that exist)
 uint32_t tail_rows_for(const Engine& e, uint32_t n) {
-    if (n > kTailRowsMax) return (uint32_t)kTailFusedRows;          // 129 ... 256 live games: the fused family
+    if (n >= e.opt.spec_fused_from || n > kTailRowsMax) return (uint32_t)kTailFusedRows;          // the fused family
     return n >= e.opt.spec_rows128_from ? 128u : n >= e.opt.spec_rows64_from ? 64u : 32u;
 }
 bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
     if (e.opt.spec_eval == 0 || n < 1 || cfg.iterations < 1) return false;
-    const bool cluster_family = n <= std::min<uint32_t>(e.opt.spec_max_games, kTailRowsMax);
-    const bool fused_family = n > kTailRowsMax && n <= std::min<uint32_t>(e.opt.spec_fused_games, kTailMaxSlots);
-    return (cluster_family || fused_family) && nn_tail_available(e, (int)tail_rows_for(e, n));
+    const uint32_t rows = tail_rows_for(e, n);
+    const bool in_reach = rows == (uint32_t)kTailFusedRows ? n <= std::min<uint32_t>(e.opt.spec_fused_games, kTailMaxSlots)
+                                                           : n <= std::min<uint32_t>(e.opt.spec_max_games, kTailRowsMax);
+    return in_reach && nn_tail_available(e, (int)rows, (int)n);
 }
 
 Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {

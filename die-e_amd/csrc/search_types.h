@@ -126,7 +126,8 @@ struct DeliverOut { float* ps; float* planes; int8_t* outcome; uint32_t* game; }
 // What rides in a launch beside the demanded leaves: every game's share of candidates (virtual descents), the candidates beyond the shares
 // where rows are scarce (extra_rows: they take what other games leave free), and the children of a demanded leaf (child_rows: the one
 // parent whose expanding iteration -- the key of its children's dice -- is known before it is expanded).
-constexpr uint32_t kTailMaxSlots = 256;   // live games (all batches of the call) up to which a move-step's search may run this way (option spec_max_games)
+constexpr uint32_t kTailMaxSlots = 256;   // live games (all batches of the call) up to which a move-step's search may run this way: one workgroup per CU
+                                          // (options spec_max_games <= 128 on the cluster family's launches, spec_fused_games for 129 ... 256 on the fused family's)
 constexpr int kTailFusedRows = 512;      // rows of a tail launch at 129 ... 256 live games: the 4-board pair tower + k_policy_fc (the fused family, like those games' plain evaluations)
 constexpr uint32_t kTailRowsMax = 128;    // rows of a tail launch at most: 32 (k_tower_cl<1, 8>, ~95 us), 64 (<2, 8>, ~125 us) or 128 (<4, 8>, ~172 us) -- one
                                           // arithmetic, so a row's bits do not depend on which of them evaluated it; the more games share a launch,
@@ -147,7 +148,7 @@ struct Tail {
     uint32_t launches;      // iterations + 1
     uint32_t iterations;
     uint32_t rollout_steps; // virtual descents per game and launch at most
-    uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128)
+    uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128; 512 at 129 ... 256 live games)
     uint32_t child_rows;    // children of a demanded leaf (created ahead: their dice are keyed by the iteration that will expand it) that ride in its launch at most (0: off)
     uint32_t extra_rows;    // candidates a game may find beyond its share of a full launch's rows: they take what other games left free (0: off)
 };

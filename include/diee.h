@@ -129,7 +129,7 @@ typedef struct {
     double   band_seconds[9];
     uint64_t band_launches[9]; /* sampled evaluations                                                                              */
     double   band_flops[9];
-    /* the tail of a batch (<= spec_max_games = 96 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
+    /* the tail of a batch (<= spec_max_games = 96 and 129 ... spec_fused_games = 256 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
      * they needed (one per iteration without it), and the rows those launches evaluated on speculation (all batches of the call,
      * reported with batch 0) */
     uint64_t tail_iterations;
@@ -178,10 +178,11 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *   spec_rows64_from, spec_rows128_from   live games from which a tail launch carries 64 / 128 rows instead of 32 (defaults 5 / 10)
  *   spec_extra_rows       candidates a game may find beyond its share of a tail launch whose rows are scarce: they take what other games leave free (default 2)
  *   spec_child_rows       children of a leaf that waits for its evaluation that are evaluated in the same tail launch at most (default 16; 0: off)
+ *   spec_fused_games      129 ... this many live games search that way too, on 512-row launches of the fused kernel family (default 256 = at most; 0: off)
  *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
  *                                 with several ranks per host: what each may retain)
  *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)
- *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps (virtual descents per game and launch, default 24), fused_heads, cluster_heads, cluster_init, trace_steps,
+ *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps (virtual descents per game and launch, default 24), spec_fused_from, fused_heads, cluster_heads, cluster_init, trace_steps,
  *   trace_dispatch, test_starve_at                                                  development / test switches
  * Unknown key or malformed value: DIEE_ERR_ARG.  Not for a tic-tac-toe ctx (DIEE_ERR_UNSUPPORTED). */
 diee_status diee_set_option(diee_ctx*, const char* key, const char* value);

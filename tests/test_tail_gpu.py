@@ -1,4 +1,4 @@
-"""The tail of a batch (<= 96 live games by default, 128 at most; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
+"""The tail of a batch (<= 96 and 129 ... 256 live games by default; die-e_amd/csrc/search_types.h `Tail`, k_tail): the iterations of a search run inside one
 launch for as long as every selected leaf's evaluation is at hand, and the launches in between carry speculative rows.  Nothing of
 that may show in a result: every case here holds the engine -- with the path on, with it off, and with the speculation alone off --
 to the CPU oracle's lockstep search BIT FOR BIT, and asserts that the path really ran (`tail_iterations`) and really saved launches."""
