@@ -361,6 +361,16 @@ def main(argv=None, engine_factory=None):
         dist.init_process_group(backend)           # "nccl" is RCCL on ROCm
 
     import diee_amd
+    if dist is not None and world > 1 and not shares_gpu and engine_factory is None:
+        # a narrowed HIP_VISIBLE_DEVICES may be one GPU per rank (a launcher's doing) or the same GPU for every rank (a one-GPU box): the
+        # PCI bus ids tell -- two ranks on one id share it, whatever the ordinals say
+        try:
+            mine = diee_amd.device_pci_bus_id(dev)
+            ids = [None] * world
+            dist.all_gather_object(ids, mine)
+            shares_gpu = ids.count(mine) > 1
+        except Exception as ex:                      # (no GPU: the engine below refuses anyway)
+            sys.stderr.write(f"[bench] rank {rank}: PCI bus ids not compared ({ex})\n")
     pci = None
     if dist is not None and backend == "nccl" and engine_factory is None:
         # two HIP runtimes live in this process (PyTorch's bundled one and the system one behind libdiee.so): before the engine is
