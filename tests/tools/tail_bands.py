@@ -1,3 +1,6 @@
+"""The tail of a batch by live games: `DIEE_TRACE_STEPS=1 python3 bench.py ... 2> trace.txt; python3 tests/tools/tail_bands.py trace.txt` prints, per band of
+live games, the move-steps, the search iterations, the network launches that carried rows, launches per iteration, iterations per launch and the
+speculative rows per launch (profiles/r05B_*, r05G_*, r05H_*).  Reads the engine's trace lines only."""
 import sys,re,collections
 agg=collections.defaultdict(lambda:[0,0,0,0])
 for l in open(sys.argv[1]):

@@ -1,3 +1,5 @@
+"""The tail of ONE traced batch move-step by move-step (every 6th): live games, launches per 100 iterations, speculative rows per launch
+(`DIEE_TRACE_STEPS=1 python3 bench.py --games 256 ... 2> trace.txt`; profiles/r05M_tail_by_phase_256_games.txt)."""
 import sys,re
 rows=[]
 for l in open(sys.argv[1]):
