@@ -29,7 +29,9 @@ const OptEntry kOptions[] = {
     {"shared_gpu", &Options::shared_gpu, nullptr, nullptr},
     {"cl_grow", &Options::cl_grow, nullptr, nullptr}, {"expand2", &Options::expand2, nullptr, nullptr},
     {"expand2c", &Options::expand2c, nullptr, nullptr}, {"spec_eval", &Options::spec_eval, nullptr, nullptr},
-    {"spec_rollout_steps", nullptr, &Options::spec_rollout_steps, nullptr}, {"spec_max_games", nullptr, &Options::spec_max_games, nullptr}, {"spec_extra_rows", nullptr, &Options::spec_extra_rows, nullptr}, {"spec_child_rows", nullptr, &Options::spec_child_rows, nullptr}, {"spec_fused_games", nullptr, &Options::spec_fused_games, nullptr}, {"spec_fused_from", nullptr, &Options::spec_fused_from, nullptr},
+    {"spec_rollout_steps", nullptr, &Options::spec_rollout_steps, nullptr}, {"spec_max_games", nullptr, &Options::spec_max_games, nullptr},
+    {"spec_extra_rows", nullptr, &Options::spec_extra_rows, nullptr}, {"spec_child_rows", nullptr, &Options::spec_child_rows, nullptr},
+    {"spec_fused_games", nullptr, &Options::spec_fused_games, nullptr}, {"spec_fused_from", nullptr, &Options::spec_fused_from, nullptr},
     {"spec_rows64_from", nullptr, &Options::spec_rows64_from, nullptr}, {"spec_rows128_from", nullptr, &Options::spec_rows128_from, nullptr},
     {"path_cap", nullptr, &Options::path_cap, nullptr}, {"nodes_per_expansion", nullptr, &Options::nodes_per_expansion, nullptr},
     {"deliver_stage_rows", nullptr, &Options::deliver_stage_rows, nullptr}, {"deliver_rows_per_game", nullptr, &Options::deliver_rows_per_game, nullptr},

@@ -161,3 +161,16 @@ def test_cpp_host_mirror_compiles_links_and_fails_loudly_without_a_gpu(tmp_path)
         pytest.skip("a GPU is present: the run is tests/test_host_gpu.py's")
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"no HIP device" in p.stderr
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """diee_set_option's keys (the table in csrc/engine.cpp) and the list in include/diee.h's comment say the same names"""
+    import re
+    src = open(os.path.join(ROOT, "die-e_amd", "csrc", "engine.cpp")).read()
+    table = src[src.index("const OptEntry kOptions[]"):src.index("const OptEntry* find_option")]
+    keys = re.findall(r'\{"([a-z0-9_]+)",', table)
+    assert len(keys) >= 25 and len(set(keys)) == len(keys)
+    hdr = open(os.path.join(ROOT, "include", "diee.h")).read()
+    doc = hdr[hdr.index("diee_create, as a development override"):hdr.index("diee_status diee_set_option")]
+    missing = [k for k in keys if not re.search(r"\b%s\b" % k, doc)]
+    assert not missing, missing
