@@ -286,6 +286,86 @@ def pin_to_gpu_numa(torch, dev):
         return f"not pinned ({type(e).__name__}: {e})"
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_group(cmd, env, timeout_s, hold_json):
+    """one child process group (start_new_session): stdout passed through line by line -- the last JSON line held back when
+    `hold_json` --, killed as a group (by its own pgid, never by pattern) when `timeout_s` expires or this process is told to stop"""
+    import signal
+    import subprocess
+    import threading
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, start_new_session=True)
+    held = []
+
+    def pump():
+        for raw in p.stdout:
+            line = raw.decode(errors="replace")
+            if hold_json and line.startswith("{"):
+                held.append(line)
+            else:
+                sys.stdout.write(line); sys.stdout.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+
+    def stop(signum, _frame):
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+    old = {sg: signal.signal(sg, stop) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        try:
+            rc = p.wait(timeout=timeout_s or None)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write(f"[bench] the ranks did not finish within {timeout_s} s: stopping them\n")
+            for sg in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(p.pid, sg)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=20)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = 124
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    th.join(timeout=30)
+    return rc, held
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` typed alone (N > 1, no RANK in the environment -- the driver's command shape): THIS process
+    becomes the launcher.  It has imported nothing that can initialise the GPU and never will; it starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same argv>`
+    as a CHILD process (never an exec), passes rank 0's JSON line through and exits with the child's return code -- non-zero
+    when any rank failed (torch.distributed.run stops the others) or the ranks outlived --launch-timeout.
+    --learn-loop (BASELINE configs[4]) at N > 1: a second group of N ranks runs the learn loop behind the self-play legs
+    (scripts/learn_config5.py: DistributedDataParallel over RCCL) and its report joins the line as `learn_loop`."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between the ranks' processes needs it on this driver
+    child_argv = [a for a in argv if a != "--learn-loop"]
+    run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1"]
+    rc, held = _run_group(run + ["--master-port", str(_free_port()), os.path.abspath(__file__)] + child_argv, env, args.launch_timeout, args.learn_loop)
+    if args.learn_loop and held:
+        line = json.loads(held[-1])
+        if rc == 0:
+            games = args.learn_games or args.games
+            rc2, rep = _run_group(run + ["--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "learn_config5.py"),
+                                         str(games), "2", str(args.iterations)], env, args.launch_timeout, True)
+            line["learn_loop"] = json.loads(rep[-1]) if rc2 == 0 and rep else {"failed": f"rc {rc2}"}
+            rc = rc or rc2
+        print(json.dumps(line)); sys.stdout.flush()
+    return rc
+
+
 def main(argv=None, engine_factory=None):
     """argv / engine_factory: tests/test_dist_cpu.py drives this very function on gloo ranks with a stand-in engine
     (DIEE_BENCH_BACKEND=gloo: CPU tensors for the reductions, no torch.cuda call); the driver and users run it as a script."""
@@ -312,6 +392,7 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--learn-loop", action="store_true", help="also run BASELINE configs[4] (learn_iterations=2, self_play_iterations=4, num_epochs=4, "
                     "training_batch_size=256) after the self-play legs and report its wall-clock per phase as `learn_loop` (adds minutes)")
     ap.add_argument("--learn-games", type=int, default=None, help="num_self_play_batches of the --learn-loop run (default: --games)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="N > 1 typed alone: stop the ranks this process started after so many seconds (0 = never)")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config]
     custom = args.games is not None or args.iterations is not None
@@ -323,14 +404,25 @@ def main(argv=None, engine_factory=None):
         print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game, games=args.cpu_games)))
         return
 
+    if args.gpus > 1 and "RANK" not in os.environ and engine_factory is None:
+        # the driver's own command shape, `python bench.py --gpus N ...`: start the N ranks as a child process group (nothing that can
+        # touch the GPU has been imported by this process, and nothing will be)
+        raise SystemExit(launch_ranks(args, list(sys.argv[1:] if argv is None else argv)))
+    if engine_factory is None and os.environ.get("DIEE_BENCH_ENGINE"):
+        # tests only (tests/test_dist_cpu.py): "module:attr" of a stand-in engine for boxes without a GPU; the line says so (`engine`)
+        import importlib
+        mod, _, attr = os.environ["DIEE_BENCH_ENGINE"].partition(":")
+        engine_factory = getattr(importlib.import_module(mod), attr)
+
     import importlib
     ddist = importlib.import_module("die-e_amd.dist")
     rank, local_rank, world = ddist.rank_world()
     if args.gpus != world:
-        # `--gpus N` names the job size; the ranks come from the launcher (python -m torch.distributed.run --nproc-per-node N ...).
-        # Alone, `python bench.py --gpus 8` would run ONE rank and report n_gpus = 1 under an 8-GPU flag: refuse instead.
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
-                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+        # inside a rank `--gpus N` names the job size and must equal the launcher's WORLD_SIZE (a rank that reported n_gpus = 1 under
+        # an 8-GPU flag would be a wrong line, not a slow one)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: `python bench.py --gpus {args.gpus} ...` starts its own ranks; under "
+                         f"a launcher use `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {args.gpus} ...`")
     backend = os.environ.get("DIEE_BENCH_BACKEND", "nccl")      # "gloo": the CPU test of this function
     red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
@@ -659,7 +751,10 @@ def main(argv=None, engine_factory=None):
         if affinity is not None:
             out["host_affinity_rank0"] = affinity
         out["scale_note"] = ("N>1 never run on hardware by the build (gpurun boxes have one GPU); ranks are independent workers (no data-path collective): expected weak scaling = N x the 1-GPU value; "
-                                 "this code path has run under torch.distributed.run at world size 1 on RCCL (tests/test_dist_gpu.py) and at world sizes 2 and 8 on gloo (tests/test_dist_cpu.py)")
+                                 "`python bench.py --gpus N` starts its own N ranks (child torch.distributed.run); this code path has run at world size 1 on RCCL and at world size 2 on one shared GPU "
+                                 "(tests/test_dist_gpu.py) and at world sizes 2 and 8 on gloo (tests/test_dist_cpu.py)")
+        if os.environ.get("DIEE_BENCH_ENGINE"):
+            out["engine"] = f"STAND-IN {os.environ['DIEE_BENCH_ENGINE']} (tests only: not the HIP engine, no figure of this line is a measurement)"
         if pipe is not None:
             # NOT the headline: `value` above stays one self_play_parallel call per step, as the reference issues them
             out["value_pipelined"] = pipe["games"] / dtp

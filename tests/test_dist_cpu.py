@@ -247,3 +247,35 @@ def test_bench_main_on_eight_gloo_ranks(oracle):
     want = [len(oracle.self_play_parallel(1, 2, cfg, 1.25, 0xD1EE0001, oracle.hash_eval_fn(), oracle.game(1), ref_quirks=1, first_game_id=2 * r)["outcome"])
             for r in range(world)]
     assert want == d["fragments_per_rank"]
+
+
+def test_plain_bench_command_starts_its_own_ranks(oracle):
+    """the driver's command shape for N > 1 is the plain `python bench.py --gpus N ...`: bench.py itself must start the N ranks
+    (a child torch.distributed.run on 127.0.0.1 and a free port, before anything could touch a GPU), pass rank 0's single line
+    through and return the child's exit code.  Here: N = 2 over gloo with the stand-in engine named through DIEE_BENCH_ENGINE."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DIEE_BENCH_BACKEND="gloo", DIEE_BENCH_ENGINE="tests.test_dist_cpu:_StubEngine", OMP_NUM_THREADS="1",
+               PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--games", "3", "--iterations", "5", "--pipeline", "0", "--hbm-only-steps", "0",
+            "--no-cpu-baseline", "--launch-timeout", "600"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stats"]["games"] == 2 * 3 and len(d["fragments_per_rank"]) == 2 and d["config"]["parallelism"].startswith("dp2")
+    assert d["engine"].startswith("STAND-IN")
+    # a rank that fails makes the plain command fail too (the launcher returns its child's code): an engine that cannot be imported
+    env["DIEE_BENCH_ENGINE"] = "tests.test_dist_cpu:_NoSuchEngine"
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert q.returncode != 0 and not [l for l in q.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_rank_refuses_a_gpus_flag_that_is_not_its_world_size():
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", DIEE_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE is 1" in p.stderr

@@ -1,7 +1,8 @@
 """The multi-rank code path of bench.py on hardware: launched exactly as the driver launches it for N > 1
 (python -m torch.distributed.run ... bench.py --gpus N), here with ONE rank on the one GPU of the box.  RCCL
 initialises, torch's HIP runtime and libdiee.so's share the process, barrier + MAX / SUM reductions run on the GPU.
-The launcher is a FRESH child process (it starts before anything touches the GPU; nothing is re-exec'ed)."""
+The launcher is a FRESH child process (it starts before anything touches the GPU; nothing is re-exec'ed).
+Round 6: the plain `python bench.py --gpus 2` starts its own ranks (second test)."""
 import json
 import os
 import subprocess
@@ -44,9 +45,9 @@ def test_bench_two_ranks_on_the_one_gpu_over_gloo():
     block of game ids on a real engine; the line carries both ranks' fragment counts and the sum of their games."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DIEE_BENCH_BACKEND="gloo")
     args = ["--gpus", "2", "--steps", "1", "--iterations", "6", "--no-cpu-baseline", "--games", "16", "--pipeline", "0"]   # whole games: records exist
-    port = str(29900 + os.getpid() % 90)
-    rc, line, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", port, "bench.py"] + args, env)
+    # the PLAIN command, as the driver types it for N > 1: bench.py starts its own two ranks (child torch.distributed.run); the
+    # explicit launcher form is the next test's
+    rc, line, err = _run([sys.executable, "bench.py"] + args + ["--launch-timeout", "800"], env)
     assert rc == 0, err
     assert line is not None, err
     assert line["n_gpus"] == 2 and line["config"]["parallelism"].startswith("dp2")
