@@ -108,14 +108,6 @@ def _config5_loop(tmp_path, games, label):
     return rep, total
 
 
-def test_learn_loop_at_config5_parameters_reduced_batch(tmp_path):
-    """BASELINE configs[4] at its stated parameter values with num_self_play_batches reduced from 1024 to 64 (the quick case;
-    the full size is the next test): both learn iterations run every phase (4 pipelined self-play batches, cumulative sp-j dirs,
-    4 epochs of fp32 training, fold-back, arena vs best_model)"""
-    rep, _ = _config5_loop(tmp_path, 64, "64 games per batch")
-    assert all(r["fragments"] > 4 * 64 * 40 for r in rep)
-
-
 def test_learn_loop_config5_full_size(tmp_path):
     """BASELINE configs[4] AT ITS OWN SIZE on one GPU: learn_iterations=2, self_play_iterations=4, num_epochs=4,
     training_batch_size=256, num_self_play_batches=1024, iterations=100, temperature 1.25, arena of 400 games, the default fp32

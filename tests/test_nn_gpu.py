@@ -316,14 +316,16 @@ def test_forward_above_one_chip_pass(setup, oracle, n):
 
 
 def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
-    """end to end at config-2 geometry: the oracle's search driven by the fp32 restatement against the engine's
-    search on its bf16 network, 256 roots, iterations = 100.  The searches are chaotic in the last bit (a prior that
+    """end to end on the CLUSTER family (<= 128 boards: the arithmetic the 1024-root case below never meets) with the fp32
+    restatement evaluated where the reference evaluates it, on the CPU: the oracle's search driven by fp32 PyTorch against the
+    engine's search on its bf16 network, 48 roots, iterations = 60.  The searches are chaotic in the last bit (a prior that
     differs by 1e-6 can flip a PUCT tie), so the comparison is statistical: argmax-visit agreement and the total-variation
-    distance between the root visit distributions"""
+    distance between the root visit distributions.  (Round 6: cut from 256 roots x 100 iterations, 64 s of CPU network -- the fused
+    family at that size is what the 1024-root case covers.)"""
     import diee_amd
     from oracle.nn_ref import forward_t
     e, net, _ = setup
-    n, iters = 256, 100
+    n, iters = 48, 60
     walk = oracle.random_walk_states(31337, 40)
     states = walk[np.linspace(5, len(walk) - 1, n).astype(int)]
 
@@ -341,11 +343,12 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     tv = 0.5 * np.abs(a - b).sum(1)
     agree = (a.argmax(1) == b.argmax(1)).mean()
     same_support = ((a > 0) == (b > 0)).all(1).mean()
-    print(f"[nn-parity] search fp32 vs bf16, {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.3f}, "
+    print(f"[nn-parity] search fp32 (CPU) vs bf16 (cluster family), {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.3f}, "
           f"TV mean {tv.mean():.4f} / p95 {np.quantile(tv, 0.95):.4f} / max {tv.max():.4f}, identical support {same_support:.3f}")
     assert same_support == 1.0                  # legal plays are integer work: identical
-    # measured (round 2): agreement 0.992, TV mean 0.0010, p95 0.0100, max 0.0183; bounds = 3 x measured
-    assert agree >= 0.97 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.03 and tv.max() <= 0.06
+    # 256 roots x 100 iterations measured 0.992 / 0.0010 / 0.0100 / 0.0183 (round 2); one flipped visit of 60 moves a root's TV by 0.017,
+    # one flipped argmax of 48 roots the agreement by 0.021: bounds for the smaller sample
+    assert agree >= 0.93 and tv.mean() <= 0.005 and np.quantile(tv, 0.95) <= 0.04 and tv.max() <= 0.1
 
 
 def test_search_with_bf16_net_tracks_search_with_fp32_net_at_1024_roots(setup, oracle):
