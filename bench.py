@@ -27,8 +27,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = "r05r_mfma_busy.json", "r05r_mfma_busy_32boards.json"     # scripts/pmc_mfma.sh (round 5; the 32-board pass with DIEE_SPEC_EVAL=0)
-TRAFFIC_FILE, TRAFFIC_FILE_32 = "r05r_pmc_traffic.json", "r05r_pmc_traffic_32boards.json"       # scripts/profile_bench.sh
+PROFILE_SET = "r05r"          # ONE prefix under profiles/ for every figure this line reads from committed counter passes (scripts/profile_bench.sh + scripts/pmc_mfma.sh TAG)
+MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = f"{PROFILE_SET}_mfma_busy.json", f"{PROFILE_SET}_mfma_busy_32boards.json"     # (the 32-board pass with DIEE_SPEC_EVAL=0)
+TRAFFIC_FILE, TRAFFIC_FILE_32 = f"{PROFILE_SET}_pmc_traffic.json", f"{PROFILE_SET}_pmc_traffic_32boards.json"
 
 
 def host_cores():
@@ -101,7 +102,7 @@ def _omp_search(job):
     return out
 
 
-def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=2, games_budget_s=75.0, big_roots=1024, big_budget_s=30.0):
+def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, games=16, games_budget_s=75.0, big_roots=1024, big_budget_s=30.0, plies_per_game=0.0):
     """The reference's CPU path restated (oracle = C restatement of its serial tree / game loops, PyTorch fp32 CPU
     ResNet = what tch/libtorch gives it on a CPU-only host), timed on a bounded sample: one move-step of search on
     `n_roots` positions drawn from random self-play walks (opening, middle game and bear-off alike); the number of MCTS
@@ -114,9 +115,10 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
       B-omp  the generous variant BASELINE.md promises ("rayon over games", versus.rs:304,308, pool sized at main.rs:107-110):
              one search per root, one PROCESS per host core (the reference's rayon threads share no interpreter lock; Python
              threads would), batch-1 single-threaded network evaluations -- no cross-game batching, no serial section.
-      B-games  `games` whole games played to completion (B-ref machinery; the batch is the live games, so the network
-             runs at batch <= games): reported beside the extrapolation as `games_played_value`.
-    Returns the faster of B-ref / B-omp as `value` (games/s, extrapolated with the GPU run's expansions per game)."""
+      B-games  `games` (16) games of the real self-play loop from the opening to a ply cap that fits `games_budget_s` (B-ref machinery; network
+             batch = the live games): MEASURED plies/s -> `games_played_value`, beside the extrapolation.
+    Returns the fastest of B-ref / B-ref-1024 / B-omp as `value`: games/s EXTRAPOLATED from that sample's expansions/s with the GPU run's
+    expansions per game (`kind` says so)."""
     import multiprocessing as mp
     cores = host_cores()
     workers = max(1, min(cores, n_roots))
@@ -128,7 +130,7 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
     orc.build()
     walk = orc.random_walk_states(seed & 0xFFFF, 40)
     roots = walk[np.linspace(3, len(walk) - 1, n_roots).astype(int)]
-    out = {"unit": "games/s", "kind": "port", "cores": cores, "host_threads_visible": os.cpu_count(), "variants": {}}
+    out = {"unit": "games/s", "kind": "port, extrapolated from expansions/s", "cores": cores, "host_threads_visible": os.cpu_count(), "variants": {}}
     # ---- B-omp ----
     try:
         t_eval = max(pool.map(_omp_calibrate, [roots[i:i + 1].tobytes() for i in range(workers)]))     # per-evaluation time with every worker busy
@@ -191,24 +193,32 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
             "mean_children": st["children"] / max(st["expansions"], 1), "mean_leaf_depth": st["depth_sum"] / max(st["selections"], 1),
             "what": f"one batched search over {big_roots} roots = the metric's num_self_play_batches (serial C tree loops + fp32 PyTorch CPU ResNet on "
                     f"{cores} intra-op threads, {t_big:.2f} s per evaluation of the batch)"}
-    # ---- B-games: whole games, not an extrapolation -- `games` games of self_play_parallel played to completion at the
-    # full iteration count by the same B-ref machinery (serial C driver + tree, the network batch on every core)
+    # ---- B-games: a MEASURED run of the metric's own loop, not a search sample: `games` games of self_play_parallel played by the same B-ref
+    # machinery (serial C driver + tree, the network batch = the live games on every core) at the full iteration count, from the opening
+    # to a ply cap that fits the budget (a whole game is ~110 plies x 101 evaluations: hours at this rate); games/s = plies played per
+    # second / the plies of a game (the GPU run's mean)
     if games > 0:
-        t8 = calibrate(roots[:games])
-        while games > 1 and t8 * (iterations + 1) * 130 > games_budget_s:       # ~130 move-steps for the longest of a few games
-            games -= 1
-            t8 = calibrate(roots[:games])
         cfg = orc.MctsCfg(iterations=iterations, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+        # the first move-step alone tells what one costs (a single timed evaluation proved unreliable: 100x off on a busy host); then the
+        # measured run plays as many move-steps as fit the budget, from the opening again
         t = time.time()
-        sp = orc.self_play_parallel(1, games, cfg, 1.25, seed, orc.make_eval(fn, 1352), None, ref_quirks=1)
+        orc.self_play_parallel(1, games, cfg, 1.25, seed, orc.make_eval(fn, 1352), None, ref_quirks=1, max_steps=1)
+        t_step = max(time.time() - t, 1e-3)
+        t_g = t_step / (iterations + 1)
+        cap = int(max(1, min(400, games_budget_s / t_step)))
+        t = time.time()
+        sp = orc.self_play_parallel(1, games, cfg, 1.25, seed, orc.make_eval(fn, 1352), None, ref_quirks=1, max_steps=cap)
         dt = time.time() - t
+        plies = int(sp["plies"].sum())
+        ppg = plies_per_game or 110.0
         out["variants"]["B-games"] = {
-            "games_per_s": games / dt, "games": games, "seconds": dt, "threads": cores, "iterations": iterations,
-            "expansions_per_s": sp["stats"]["expansions"] / dt, "move_steps": int(sp["steps"]), "fragments": int(len(sp["outcome"])),
-            "plies_per_game": float(sp["plies"].mean()),
-            "what": f"{games} games of self_play_parallel played to completion (oracle driver + tree in C on one thread, fp32 PyTorch CPU "
-                    f"ResNet on {cores} intra-op threads, network batch = live games <= {games}): a measured games/s, small-batch"}
-        out["games_played_value"] = games / dt
+            "games_per_s": plies / dt / ppg, "plies_per_s": plies / dt, "games": games, "move_steps": int(sp["steps"]), "plies_played": plies,
+            "plies_per_game_assumed": ppg, "seconds": dt, "threads": cores, "iterations": iterations,
+            "expansions_per_s": sp["stats"]["expansions"] / dt, "eval_s_per_batch": t_g,
+            "what": f"{games} games of self_play_parallel, iterations = {iterations}, played from the opening for {int(sp['steps'])} move-steps "
+                    f"({plies} plies; oracle driver + tree in C on one thread, fp32 PyTorch CPU ResNet on {cores} intra-op threads, network batch = "
+                    f"the {games} live games): MEASURED plies/s, / {ppg:.1f} plies per game (the GPU run's mean) = games/s"}
+        out["games_played_value"] = plies / dt / ppg
     best = max((k for k in out["variants"] if k != "B-games"), key=lambda k: out["variants"][k]["expansions_per_s"])
     eps = out["variants"][best]["expansions_per_s"]
     out["expansions_per_s"] = eps
@@ -223,12 +233,12 @@ def cpu_baseline(iterations, seed, exp_per_game, n_roots=64, budget_s=12.0, game
     return out
 
 
-def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=480, games=2):
+def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=480, games=16, plies_per_game=0.0):
     """cpu_baseline in a child process (its own thread-pool settings; killed by PID after timeout_s): the baseline is a
     report and must never hang the bench line"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--iterations", str(iterations),
-           "--seed", str(seed), "--exp-per-game", repr(float(exp_per_game)), "--cpu-games", str(games)]
+           "--seed", str(seed), "--exp-per-game", repr(float(exp_per_game)), "--cpu-games", str(games), "--plies-per-game", repr(float(plies_per_game))]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -237,7 +247,7 @@ def cpu_baseline_guarded(iterations, seed, exp_per_game, timeout_s=480, games=2)
         why = f"rc {p.returncode}: {p.stderr.decode()[-300:]}"
     except subprocess.TimeoutExpired:
         why = f"no result within {timeout_s} s"
-    return {"value": None, "unit": "games/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {why}"}
+    return {"value": None, "unit": "games/s", "cores": host_cores(), "kind": "port, extrapolated from expansions/s", "sample": f"failed: {why}"}
 
 
 def learn_loop_leg(eng, games, iterations, timeout_s=3000):
@@ -381,7 +391,8 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--iterations", type=int, default=None, help="MCTS iterations (overrides the preset)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xD1EE0001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-games", type=int, default=2, help="whole games the CPU baseline also plays to completion (0 = extrapolation only)")
+    ap.add_argument("--cpu-games", type=int, default=16, help="games the CPU baseline also plays through the real self-play loop to a ply cap (measured plies/s; 0 = extrapolation only)")
+    ap.add_argument("--plies-per-game", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--max-steps", type=int, default=0, help="profiling aid: stop each batch after this many move-steps (0 = play to completion)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--exp-per-game", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -401,7 +412,7 @@ def main(argv=None, engine_factory=None):
     if args.iterations is None:
         args.iterations = preset["iterations"]
     if args.cpu_baseline_only:                   # child of cpu_baseline_guarded: CPU only, never touches the GPU
-        print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game, games=args.cpu_games)))
+        print(json.dumps(cpu_baseline(args.iterations, args.seed, args.exp_per_game, games=args.cpu_games, plies_per_game=args.plies_per_game)))
         return
 
     if args.gpus > 1 and "RANK" not in os.environ and engine_factory is None:
@@ -630,7 +641,14 @@ def main(argv=None, engine_factory=None):
                 doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
                 for k, v in doc["kernels"].items():
                     if k.startswith(name) and "mfma_busy_frac" in v:
-                        return {"mfma_busy_frac": v["mfma_busy_frac"], "clock_mhz": v["clock_mhz"], "us": v["duration_us"]}
+                        us = v["duration_us"]
+                        us = next(iter(us.values())) if isinstance(us, dict) else us      # (the pass that held SQ_VALU_MFMA_BUSY_CYCLES comes first)
+                        # MFMA FLOPs really ISSUED per second against the peak: a v_mfma_f32_16x16x32_bf16 keeps its SIMD busy for 16 cycles
+                        # and performs 16 384 FLOP (all-padding fragments are skipped and do not count: this is below `frac`, whose
+                        # algorithmic FLOPs include them)
+                        issued = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 16.0 * 16384.0
+                        return {"mfma_busy_frac": v["mfma_busy_frac"], "clock_mhz": v["clock_mhz"], "us": us,
+                                "mfma_issue_frac": issued / (us * 1e-6) / (PEAK_BF16_TFLOPS * 1e12) if us else None}
             except Exception:
                 pass
             return None
@@ -646,6 +664,7 @@ def main(argv=None, engine_factory=None):
                     "traffic_source": None if traffic is None else "profiles/ (separate rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
                     "mfma_busy_frac": None if busy is None else busy["mfma_busy_frac"],
                     "mfma_busy_clock_mhz": None if busy is None else busy["clock_mhz"],
+                    "mfma_issue_frac": None if busy is None else busy["mfma_issue_frac"],
                     "mfma_busy_source": None if busy is None else f"profiles/{busy_file} (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
                                                                    "of this command's first move-step, committed; busy cycles / (256 CUs x 4 SIMDs x GRBM_GUI_ACTIVE / 8); not re-measured in this run)",
                     "launches_sampled": launches / world,
@@ -678,11 +697,17 @@ def main(argv=None, engine_factory=None):
             dominant, other = ranked[0], ranked[1:]
         else:                                        # nothing was sampled (a run too short for a sample)
             dominant, other = None, []
-        e2e = tot["nn_rows"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world)
+        # end to end = node expansions/s x 1.0825 GFLOP (one evaluated state) / the dense bf16 peak -- the work the SEARCH asked
+        # for.  Rows the engine evaluated on speculation (the tail's free rows) and the reference's stale rows are NOT achieved work: they
+        # are counted beside it (`end_to_end_frac_rows_evaluated`, `speculative_row_share`), never in it.
+        e2e = tot["expansions"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world)
+        e2e_rows = tot["nn_rows"] * FLOPS_PER_EVAL / dt / 1e12 / (PEAK_BF16_TFLOPS * world)
+        spec_share = tot.get("tail_spec_rows", 0) / max(tot["nn_rows"], 1)
         if dominant is not None:
             # FIRST thing to read: the whole job against the roof -- every kernel, every launch gap, the host, the delivery of the
-            # records: network FLOPs really performed / wall time / dense bf16 peak.  `frac` below describes the dominant kernel alone.
-            dominant = dict({"end_to_end_frac": e2e}, **dominant)
+            # records.  `frac` below describes the dominant kernel alone.
+            dominant = dict({"end_to_end_frac": e2e, "end_to_end_frac_rows_evaluated": e2e_rows, "speculative_row_share": spec_share,
+                             "profile_set": f"profiles/{PROFILE_SET}_*"}, **dominant)
             # where a batch's network time goes as it shrinks: every sampled evaluation of this run (each 17th, HIP events on the
             # engine's stream) binned by the boards of its launch
             bands = []
@@ -707,7 +732,7 @@ def main(argv=None, engine_factory=None):
             # nn_evals = batch rows as the reference counts them (all N slots per iteration, stale rows included);
             # nn_rows = rows the engine really evaluated (stale rows are skipped above 256 live games)
             "nn_evals_per_s": tot["nn_evals"] / dt, "nn_rows_per_s": tot["nn_rows"] / dt,
-            "mfma_fraction_end_to_end": e2e,
+            "mfma_fraction_end_to_end": e2e, "mfma_fraction_end_to_end_rows_evaluated": e2e_rows,
             "stats": {"games": games, "plies_per_game": tot["plies"] / max(games, 1), "move_steps": tot["move_steps"],
                       "expansions_per_game": exp_per_game, "mean_children": tot["children"] / max(tot["expansions"], 1),
                       "mean_leaf_depth": tot["depth_sum"] / max(tot["selections"], 1),
@@ -765,7 +790,8 @@ def main(argv=None, engine_factory=None):
                 "batches": args.pipeline, "seconds": dtp, "games": pipe["games"], "move_steps": pipe["move_steps"],
                 "node_expansions_per_s": pipe["expansions"] / dtp, "nn_evals_per_s": pipe["nn_evals"] / dtp,
                 "nn_rows_per_s": pipe["nn_rows"] / dtp,
-                "mfma_fraction_end_to_end": pipe["nn_rows"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
+                "mfma_fraction_end_to_end": pipe["expansions"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
+                "mfma_fraction_end_to_end_rows_evaluated": pipe["nn_rows"] * FLOPS_PER_EVAL / dtp / 1e12 / (PEAK_BF16_TFLOPS * world),
                 "fused_tower_tflops": (pipe["tower_flops"] / pipe["tower_seconds"] / 1e12) if pipe["tower_seconds"] else None,
                 "fused_tower_avg_launch_us": (pipe["tower_seconds"] / max(pipe["tower_launches"], 1) * 1e6) if pipe["tower_seconds"] else None,
                 "deliver_bytes": pipe["deliver_bytes"], "host_ms_in_delivery_calls": 1e3 * pipe["deliver_seconds"],
@@ -773,7 +799,8 @@ def main(argv=None, engine_factory=None):
         if learn is not None:
             out["learn_loop"] = learn
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_guarded(args.iterations, args.seed, exp_per_game, games=args.cpu_games)
+            out["cpu_baseline"] = cpu_baseline_guarded(args.iterations, args.seed, exp_per_game, games=args.cpu_games,
+                                                       plies_per_game=tot["plies"] / max(games, 1))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

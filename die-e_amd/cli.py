@@ -132,12 +132,21 @@ def main(argv=None):
         import torch.distributed as dist
         ndev = max(torch.cuda.device_count(), 1)
         device = local_rank % ndev
-        if world > ndev and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
-            shares_gpu = True                          # ranks share a GPU: told to the engine below (diee_set_option "shared_gpu")
         if torch.cuda.is_available():
             torch.cuda.set_device(device)
         if not dist.is_initialized():
             dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # ranks that share a GPU are recognised by the PCI bus id of their device, not by counting ordinals: a box-wide
+        # HIP_VISIBLE_DEVICES=0 gives every rank "its own" device 0 (bench.py does the same)
+        from . import device_pci_bus_id
+        try:
+            mine = device_pci_bus_id(device)
+            ids = [None] * world
+            dist.all_gather_object(ids, mine)
+            shares_gpu = ids.count(mine) > 1           # told to the engine below (diee_set_option "shared_gpu")
+        except Exception as ex:                        # (no GPU: the engine below refuses anyway)
+            sys.stderr.write(f"[diee] rank {rank}: PCI bus ids not compared ({ex})\n")
+            shares_gpu = world > ndev
     eng = Engine(device)
     if shares_gpu:
         from . import load_library

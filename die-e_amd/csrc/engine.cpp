@@ -33,6 +33,7 @@ const OptEntry kOptions[] = {
     {"spec_extra_rows", nullptr, &Options::spec_extra_rows, nullptr}, {"spec_child_rows", nullptr, &Options::spec_child_rows, nullptr},
     {"spec_fused_games", nullptr, &Options::spec_fused_games, nullptr}, {"spec_fused_from", nullptr, &Options::spec_fused_from, nullptr},
     {"spec_rows64_from", nullptr, &Options::spec_rows64_from, nullptr}, {"spec_rows128_from", nullptr, &Options::spec_rows128_from, nullptr},
+    {"spec_ring_mb", nullptr, &Options::spec_ring_mb, nullptr},
     {"path_cap", nullptr, &Options::path_cap, nullptr}, {"nodes_per_expansion", nullptr, &Options::nodes_per_expansion, nullptr},
     {"deliver_stage_rows", nullptr, &Options::deliver_stage_rows, nullptr}, {"deliver_rows_per_game", nullptr, &Options::deliver_rows_per_game, nullptr},
     {"trace_steps", &Options::trace_steps, nullptr, nullptr}, {"trace_dispatch", &Options::trace_dispatch, nullptr, nullptr},

@@ -67,6 +67,8 @@ struct Options {
     uint32_t spec_extra_rows = 2;           // candidates a game may find beyond its share of a full tail launch: they take the rows other games left free
     uint32_t spec_max_games = 96;           // live games up to which a move-step's search runs in tail mode (<= 128 = kTailMaxSlots; beyond 64 a launch has fewer spare rows than games)
     uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
+    uint32_t spec_ring_mb = 8192;           // HBM the tail's ring of evaluated rows may take (MiB): (iterations + 1) launches x rows x 5.7 KB; a search whose ring
+                                            // would be larger runs one launch per iteration instead (iterations = 1600 x 512 rows: 4.7 GB)
     uint32_t path_cap = 64, nodes_per_expansion = 128;
     // output delivery
     uint32_t deliver_stage_rows = 16384, deliver_rows_per_game = 128;

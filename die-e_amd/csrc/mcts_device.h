@@ -16,6 +16,7 @@ constexpr uint32_t kDrained = 0x80000000u;
 // Tree::meta: bit 31 expanded, bit 30 the node's state is a finished game, bit 29 ... won by player +1 (both set when the node is
 // created: the virtual descents of the tail read them instead of the 32-byte state), bits 28..16 children, bits 15..0 action code
 constexpr uint32_t kMetaTerminal = 0x40000000u, kMetaWinnerPlus = 0x20000000u;
+constexpr uint32_t kMetaKeep = 0xFFFFu | kMetaTerminal | kMetaWinnerPlus;      // what an expansion keeps of a node's header (a finished ROOT is expanded like any root)
 __device__ __forceinline__ uint32_t meta_nch(uint32_t m) { return (m >> 16) & 0x1fffu; }
 __device__ __forceinline__ uint32_t meta_terminal_bits(const BgState& s) {
     const int w = bg_winner_dev(s);

@@ -48,10 +48,11 @@ __global__ void k_init_roots(Tree T, Slots S, uint32_t n) {
     store_state(&T.state[base], s);
     store_state(&S.eval_states[slot], s);
     T.visits[base] = 1.0f; T.value[base] = 0.0f; T.prior[base] = 0.0f;
-    T.parent[base] = kNone; T.first_child[base] = 0; T.meta[base] = 0xFFFFu;
+    const uint32_t m0 = 0xFFFFu | meta_terminal_bits(s);      // (a finished root: k_tail reads the bits where select_slot reads the state)
+    T.parent[base] = kNone; T.first_child[base] = 0; T.meta[base] = m0;
     T.used[slot] = 1;
     S.sel[slot] = kNone; S.sel_value[slot] = 0.0f; S.leaf[slot] = 0; S.leaf_term[slot] = 0; S.path_len[slot] = 0;
-    S.leaf_meta[slot] = 0xFFFFu;
+    S.leaf_meta[slot] = m0;
 #pragma unroll
     for (int c = 0; c < SC_COUNT; ++c) S.slot_cnt[slot * SC_COUNT + c] = 0;
 }
@@ -487,7 +488,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (lane + 64 * r < k) T.prior[base + first + lane + 64 * r] = pr[r] / sum;
-        const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+        const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & kMetaKeep);
         // (TWO == 2: this is the commit wave; the main wave may be reading this very header in its descent, so the header is
         // the main wave's to store, after the meeting point, when the priors above are visible to it)
         if (lane == 0 && TWO != 2) {
@@ -555,7 +556,7 @@ __device__ __forceinline__ void expand_body(const Tree& T, const Slots& S, const
                 T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = sc.raw[j] / sum;
                 T.parent[ci] = node; T.first_child[ci] = 0; T.meta[ci] = (uint32_t)sc.code[j] | meta_terminal_bits(cs);
             }
-            const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+            const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & kMetaKeep);
             if (lane == 0) {
                 T.first_child[base + node] = first;
                 T.meta[base + node] = nmeta;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         pre.vh = value_head_load(L.hv + (size_t)ring * 72, S.wv, lane);
         softmax_load(L.logits + (size_t)ring * 1352, lane, pre.lg);
         if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {
-            if (lane == 0) { L.state[1] = 2u; L.host[1] = 2u; __threadfence_system(); }
+            if (lane == 0) { atomicMax(&L.state[1], 2u); L.host[1] = 2u; __threadfence_system(); }
             return;
         }
         TL_STAMP(1);
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
                             if (cl >= ahead_hi) { D.t.crow[cl] = 0; D.t.cval[cl] = 0.0f; }       // (below: evaluated ahead, or cleared at the take-in)
                         }
                     }
-                    const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & 0xFFFFu);
+                    const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & kMetaKeep);
                     if (lane == 0) X.set_header(leaf, nmeta, first);
                     used = first + (uint32_t)k;
                     cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
@@ -1068,9 +1069,12 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     if (lane == 0) store_counters(S, slot, cn);
     TL_STAMP(3);
     if (slot == 0 && lane == 0) {
-        L.state[0] = it; L.state[1] = done ? 1u : 0u;
+        // (a meeting that timed out in ANY workgroup left 2 in state[1]: it stays -- atomicMax, 0 < 1 < 2 -- and tail_run takes the starved path)
+        const uint32_t was = atomicMax(&L.state[1], done ? 1u : 0u);
+        const uint32_t now = was > (done ? 1u : 0u) ? was : (done ? 1u : 0u);
+        L.state[0] = it;
         if (!done) L.state[2] += 1u;
-        L.host[0] = it; L.host[1] = done ? 1u : 0u; L.host[2] = A.q;
+        L.host[0] = it; L.host[1] = now; L.host[2] = A.q;
         __threadfence_system();
     }
 }

@@ -259,6 +259,12 @@ uint32_t tail_rows_for(const Engine& e, uint32_t n) {
 bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
     if (e.opt.spec_eval == 0 || n < 1 || cfg.iterations < 1) return false;
     const uint32_t rows = tail_rows_for(e, n);
+    if (rows < n) return false;      // (options spec_rows64_from / spec_rows128_from can ask for fewer rows than games: every live game needs its demanded row)
+    // the ring of evaluated rows grows with the iterations ((iterations + 1) launches x rows x (1352 + 72) floats; crow / cval: 256 x node_cap words):
+    // beyond option spec_ring_mb the search runs one launch per iteration instead of failing an allocation in mid-batch
+    const uint32_t ring_rows = rows > kTailRowsMax ? (uint32_t)kTailFusedRows : kTailRowsMax;
+    const double ring_mb = ((double)(cfg.iterations + 1) * ring_rows * (1352 + 72 + 8 + 1) * 4.0 + (double)kTailMaxSlots * ((double)(cfg.iterations + 1) * std::max<uint32_t>(e.opt.nodes_per_expansion, 1) + 64) * 8.0) / 1048576.0;
+    if (ring_mb > (double)e.opt.spec_ring_mb) return false;
     const bool in_reach = rows == (uint32_t)kTailFusedRows ? n <= std::min<uint32_t>(e.opt.spec_fused_games, kTailMaxSlots)
                                                            : n <= std::min<uint32_t>(e.opt.spec_max_games, kTailRowsMax);
     return in_reach && nn_tail_available(e, (int)rows, (int)n);
@@ -313,11 +319,15 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
         done = B.tl_host[1] != 0;
         chunk = 4;
     }
-    uint32_t words[4] = {0, 0, 0, 0};
+    uint32_t words[4] = {0, 0, 0, 0}, flag_word = 0;
     e.d2h(words, L.state, 4);
+    e.d2h(&flag_word, e.flags_dev.p, 1);
     e.sync();
-    // (a meeting that timed out raised the starved bit: cluster_starved() repeats the search launch by launch)
-    if (!done && !(words[1] == 2u)) throw EngineError(DIEE_ERR_HIP, "tail search: the iterations did not complete");
+    // a meeting that timed out raised the starved bit (and left 2 in the state word): this search is void, cluster_starved() repeats it
+    // launch by launch -- whatever the done word says (a workgroup that gave up left its game's record unsaved)
+    const bool starved = (flag_word & 4u) != 0u || words[1] == 2u;
+    if (!done && !starved) throw EngineError(DIEE_ERR_HIP, "tail search: the iterations did not complete");
+    if (starved) { B.tl_prev_need = 0; return; }
     if (e.opt.trace_steps)
         fprintf(stderr, "[diee] tail: %u games, %u iterations on %u launches with rows (%u pairs sent), %u speculative rows\n", n, cfg.iterations, words[2], sent, words[3]);
     B.tl_prev_need = words[2];
@@ -325,7 +335,8 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
 }
 
 // alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round / seg (segment table uploaded, the
-// Dirichlet samples of this move-step in pinned buffer `buf`).  Enqueues only: no host synchronisation.
+// Dirichlet samples of this move-step in pinned buffer `buf`).  Above the tail's reach it enqueues only; a tail search (tail_run) looks at
+// its done word between chunks of launches, i.e. synchronises a few times per move-step.
 void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, int buf, uint32_t flags) {
     SearchBufs& B = *e.search;
     const Tree T = tree_view(B);

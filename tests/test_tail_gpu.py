@@ -147,3 +147,48 @@ def test_tail_with_batches_side_by_side(eng, oracle):
         for key in KEYS:
             assert o["stats"][key] == r["stats"][key], key
     assert out[0]["stats"]["tail_iterations"] > 0
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_finished_roots_in_the_tail(eng, oracle, quirks):
+    """diee_mcts_batch does not refuse a root whose game is over (round-5 advisor): with children (the loser is to move and has plays:
+    every child is a finished game) and without (the side to move has no checker left: every selection ends on the root itself).  The
+    looping kernel tells a finished game from the node header's bits where the launch-per-iteration path reads the state: both equal the oracle."""
+    walk = oracle.random_walk_states(123, 60)
+    mid = walk[200:202].copy()
+    fin = walk[walk["off"].max(axis=1) >= 13][:2].copy()
+    for s in fin:                                     # player -1 (negative points, bar[0], off[0]) has borne off everything
+        s["pts"][s["pts"] < 0] = 0; s["bar"][0] = 0; s["off"][0] = 15
+    fin[0]["player"] = 1                              # the loser to move: legal plays exist, every child is a finished game
+    fin[1]["player"] = -1                             # the winner "to move": no checker, no play, the root is the only node
+    states = np.concatenate([fin[:1], mid[:1], fin[1:], mid[1:]])
+    n, iters = len(states), 24
+    ocfg, gcfg = cfgs(oracle, iters)
+    gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32)
+    roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 3, gids, rds, quirks)
+    for spec in (1, 0):
+        eng.set_option("spec_eval", spec)
+        try:
+            r = eng.alpha_mcts_parallel(states, gcfg, SEED, 3, gids, rds, ref_quirks=bool(quirks))
+        finally:
+            eng.set_option("spec_eval", 1)
+        assert r["probs"].tobytes() == probs.tobytes(), spec
+        assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all(), spec
+        for key in KEYS:
+            assert r["stats"][key] == ostats.as_dict()[key], (spec, key, r["stats"][key], ostats.as_dict()[key])
+
+
+def test_row_thresholds_that_leave_fewer_rows_than_games_fall_back(eng, oracle):
+    """options spec_rows64_from / spec_rows128_from can ask for 64-row launches at 80 games (round-5 advisor): a launch must hold every
+    live game's demanded row, so such a move-step runs one launch per iteration instead -- same bits, no tail iterations"""
+    n, iters = 80, 12
+    states = roots_of(oracle, n, "mid")
+    ocfg, gcfg = cfgs(oracle, iters)
+    gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
+    _, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 1, gids, rds, 1)
+    eng.set_options(spec_rows128_from=200)
+    try:
+        r = eng.alpha_mcts_parallel(states, gcfg, SEED, 1, gids, rds, ref_quirks=True)
+    finally:
+        eng.set_options(spec_rows128_from=10)
+    assert r["probs"].tobytes() == probs.tobytes() and r["stats"]["tail_iterations"] == 0
