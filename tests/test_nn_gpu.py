@@ -336,8 +336,9 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     ocfg = oracle.MctsCfg(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     gcfg = diee_amd.MctsConfig(iterations=iters, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
     gids = np.arange(n, dtype=np.uint32); rds = np.zeros(n, dtype=np.uint32)
-    _, probs, _, _ = oracle.alpha_mcts_parallel(1, states, ocfg, oracle.make_eval(fn, 1352), None, 0xD1EE0001, 0, gids, rds, 1)
+    roots, probs, _, _ = oracle.alpha_mcts_parallel(1, states, ocfg, oracle.make_eval(fn, 1352), None, 0xD1EE0001, 0, gids, rds, 1)
     r = e.alpha_mcts_parallel(states, gcfg, 0xD1EE0001, 0, gids, rds, ref_quirks=True)
+    assert (r["n_children"] == np.array([len(x["children"]) for x in roots], dtype=np.uint32)).all()     # legal plays are integer work: identical
     ok = ~np.isnan(probs).any(1)
     a, b = np.nan_to_num(probs[ok]), np.nan_to_num(r["probs"][ok])
     tv = 0.5 * np.abs(a - b).sum(1)
@@ -345,10 +346,11 @@ def test_search_with_bf16_net_tracks_search_with_fp32_net(setup, oracle):
     same_support = ((a > 0) == (b > 0)).all(1).mean()
     print(f"[nn-parity] search fp32 (CPU) vs bf16 (cluster family), {ok.sum()} roots x {iters} iterations: argmax agreement {agree:.3f}, "
           f"TV mean {tv.mean():.4f} / p95 {np.quantile(tv, 0.95):.4f} / max {tv.max():.4f}, identical support {same_support:.3f}")
-    assert same_support == 1.0                  # legal plays are integer work: identical
-    # 256 roots x 100 iterations measured 0.992 / 0.0010 / 0.0100 / 0.0183 (round 2); one flipped visit of 60 moves a root's TV by 0.017,
-    # one flipped argmax of 48 roots the agreement by 0.021: bounds for the smaller sample
-    assert agree >= 0.93 and tv.mean() <= 0.005 and np.quantile(tv, 0.95) <= 0.04 and tv.max() <= 0.1
+    # measured on this sample (round 6): 0.979 / 0.0009 / 0.0079 / 0.0167, the VISITED children identical on 47 of 48 roots (60 iterations do
+    # not visit every child of a root: one flipped visit changes the support); 256 roots x 100 iterations measured 0.992 / 0.0010 / 0.0100 / 0.0183.
+    # One flipped visit of 60 moves a root's TV by 0.017, one flipped argmax of 48 roots the agreement by 0.021: bounds = 3 flips
+    assert same_support >= 0.93
+    assert agree >= 0.93 and tv.mean() <= 0.003 and np.quantile(tv, 0.95) <= 0.035 and tv.max() <= 0.06
 
 
 def test_search_with_bf16_net_tracks_search_with_fp32_net_at_1024_roots(setup, oracle):

@@ -150,16 +150,17 @@ def main():
                 continue
             variants = [("lockstep (today's k_tail policy)", dict(lockstep=1, cand_max=24)),
                         ("free, demanded only", dict(child_rows=0, cand_max=0)),
-                        ("free, cand first + children + cands (order 1)", dict(order=1)),
-                        ("free, order 2 (children first when the descent deepens)", dict(order=2))]
+                        ("free, 8 cands then children (order 0)", dict(order=0)),
+                        ("free, first cand, children, cands (order 1)", dict(order=1))]
             if not args.quick:
-                variants += [("free, order 0 (cands then children)", dict(order=0)),
-                             ("free, order 2, <= 2 speculative rows per game", dict(order=2, share_cap=2)),
-                             ("free, order 2, <= 4 speculative rows per game", dict(order=2, share_cap=4)),
-                             ("free, order 2 + root children in the root launch", dict(order=2, root_children=1)),
-                             ("free, order 1, the games behind first (prio 1)", dict(order=1, prio=1)),
-                             ("free, order 1, the games behind take all (prio 2)", dict(order=1, prio=2)),
-                             ("free, order 1, prio 1, 16 candidates", dict(order=1, prio=1, cand_max=16))]
+                variants += [("free, 8 cands, no children", dict(order=0, child_rows=0)),
+                             ("free, 16 cands then children", dict(order=0, cand_max=16)),
+                             ("free, 24 cands then children, 48 descents", dict(order=0, cand_max=24, rollouts=48)),
+                             ("free, 8 cands then children, games behind first (prio 1)", dict(order=0, prio=1)),
+                             ("free, 8 cands then children, games behind take all (prio 2)", dict(order=0, prio=2)),
+                             ("free, 16 cands then children, prio 1", dict(order=0, cand_max=16, prio=1)),
+                             ("free, 16 cands then children, prio 1 + root children", dict(order=0, cand_max=16, prio=1, root_children=1)),
+                             ("free, order 2 (children first when the descent deepens)", dict(order=2))]
             for name, kw in variants:
                 if kw.get("lockstep") and m > 512:
                     continue
