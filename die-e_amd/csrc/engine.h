@@ -67,6 +67,12 @@ struct Options {
     uint32_t spec_extra_rows = 2;           // candidates a game may find beyond its share of a full tail launch: they take the rows other games left free
     uint32_t spec_max_games = 96;           // live games up to which a move-step's search runs in tail mode (<= 128 = kTailMaxSlots; beyond 64 a launch has fewer spare rows than games)
     uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
+    int free_eval = 1;                      // the free-running search (search_types.h, Free) at free_min_games ... free_max_games live games; 0: one launch per iteration there
+    uint32_t free_min_games = 257, free_max_games = 768;     // (<= 1024: k_free_pack runs one thread per game)
+    uint32_t free_rows1024_from = 449;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512
+    uint32_t free_rollout_steps = 12, free_cand_max = 6;     // virtual descents / candidates per game and round at most
+    uint32_t free_ring = 128;               // launches whose rows stay in its ring (a row that aged out is evaluated again: same bits)
+    uint32_t free_lds_nodes = 3072;         // cap of the tree nodes k_free stages in LDS per game (tests lower it to reach the in-place path)
     uint32_t spec_ring_mb = 8192;           // HBM the tail's ring of evaluated rows may take (MiB): (iterations + 1) launches x rows x 5.7 KB; a search whose ring
                                             // would be larger runs one launch per iteration instead (iterations = 1600 x 512 rows: 4.7 GB)
     uint32_t path_cap = 64, nodes_per_expansion = 128;

@@ -96,6 +96,10 @@ void launch_expand(hipStream_t st, const Tree& T, const Slots& S, const Segs& G,
 // the tail of a batch (search_types.h, Tail): launch number q of a move-step's search -- takes in the rows of tower launch q - 1, runs
 // iterations while every live game's selected leaf has its evaluation, plans the rows of tower launch q
 void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Tail& L, uint32_t q);
+// the free-running search (search_types.h, Free): round q -- k_free takes in the rows of tower launch q - 1, runs every game's own iterations,
+// lists its wishes; k_free_pack grants the rows of tower launch q
+void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Free& F, uint32_t q);
+uint32_t free_lds_nodes_for(uint32_t n, uint32_t cus);      // nodes of a game's tree k_free stages in LDS when n games share `cus` CUs
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
 // rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
 // count also goes to rows_log[log_idx])

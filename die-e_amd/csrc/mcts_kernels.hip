@@ -1079,6 +1079,453 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     }
 }
 
+// ---- k_free: the free-running search (search_types.h, Free) -------------------------------------------------------------------------
+// One wave per live game, nobody waits for anybody.  Per launch a game (a) stages its tree's statistics in LDS (its share of the CU's
+// 160 KB: `lds_nodes` nodes, the rest is read in place) and takes in the rows the previous launch evaluated for it, (b) runs ITS OWN
+// iterations -- k_tail's body, i.e. expand_body's / select_slot's operations in their order -- for as long as its selected leaf is a
+// finished game or has its evaluation in the ring and the flag words it needs are final, (c) lists its wishes for the next launch.
+// What couples the games of a batch (Q14): a game whose leaf is a finished game needs `node_selected` of its iteration, which is final
+// once it reads 1 or once every game of the batch has published that iteration's selection; the batch's first slot needs the count of
+// stale initial slots while some game has never selected a node.  Both are read LIVE (agent-scope atomics; a game publishes its flags,
+// then its progress) and polled for a bounded few microseconds; a game that still cannot tell stops for this round -- that changes
+// when things are computed, never what.  The game furthest behind can always go on (everybody has published its iteration), so
+// every launch pair completes at least one iteration of it: `iterations` pairs always suffice.
+constexpr int kFreeSpin = 48;
+constexpr uint32_t kFreeRowBits = 12;                        // crow = ((launch << kFreeRowBits) | row) + 1
+struct FreeArgs { Free F; uint32_t q; };
+__host__ __device__ constexpr size_t free_lds_bytes(uint32_t ln) {
+    return (size_t)ln * 36u + sizeof(WaveScratch) + sizeof(float) * kMaxPlays + sizeof(uint16_t) * kMaxPlays + sizeof(uint32_t) * 64u;
+}
+// the tree through LDS with a run-time capacity: nodes below `ln` live there (and in HBM, written through), the others in HBM alone
+struct TreeF {
+    const Tree& T; size_t base; uint32_t ln;
+    float *lvis, *lval, *lpri; uint32_t *lmeta, *lfc;
+    __device__ __forceinline__ float vis(uint32_t i) const { return i < ln ? lvis[i] : T.visits[base + i]; }
+    __device__ __forceinline__ float val(uint32_t i) const { return i < ln ? lval[i] : T.value[base + i]; }
+    __device__ __forceinline__ float pri(uint32_t i) const { return i < ln ? lpri[i] : T.prior[base + i]; }
+    __device__ __forceinline__ uint32_t meta(uint32_t i) const { return i < ln ? lmeta[i] : T.meta[base + i]; }
+    __device__ __forceinline__ uint32_t fc(uint32_t i) const { return i < ln ? lfc[i] : T.first_child[base + i]; }
+    __device__ __forceinline__ void add(uint32_t i, float v) const {          // visits += 1, value += v (simple_mcts.rs:96-103, one node)
+        const float nv = vis(i) + 1.0f, nw = val(i) + v;
+        if (i < ln) { lvis[i] = nv; lval[i] = nw; }
+        T.visits[base + i] = nv; T.value[base + i] = nw;
+    }
+    __device__ __forceinline__ void set_header(uint32_t i, uint32_t m, uint32_t f) const {
+        if (i < ln) { lmeta[i] = m; lfc[i] = f; }
+        T.meta[base + i] = m; T.first_child[base + i] = f;
+    }
+};
+__device__ __forceinline__ uint32_t free_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n, SearchParams P, float c, FreeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char free_smem[];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n) return;
+    const Free& F = A.F;
+    const int lane = threadIdx.x;
+    if (F.state[0] != 0u) return;                               // every game was done when the previous round was packed
+    uint32_t it = F.prog[slot];
+    if (it >= F.iterations) { if (lane == 0) F.wish_n[slot] = it << 8; return; }
+    const uint32_t ln = F.lds_nodes;
+    float* lvis = (float*)free_smem; float* lval = lvis + ln; float* lpri = lval + ln; float* lcval = lpri + ln;
+    float* vvis = lcval + ln; float* vval = vvis + ln;
+    uint32_t* lmeta = (uint32_t*)(vval + ln); uint32_t* lfc = lmeta + ln; uint32_t* lcrow = lfc + ln;
+    WaveScratch& ws = *reinterpret_cast<WaveScratch*>(lcrow + ln);
+    float* raw = reinterpret_cast<float*>(&ws + 1);
+    uint16_t* code = reinterpret_cast<uint16_t*>(raw + kMaxPlays);
+    uint32_t* cand = reinterpret_cast<uint32_t*>(code + kMaxPlays);
+    float* lgs = (float*)&ws.keyA[0];                           // the logits row, staged over the dedup keys once the plays are enumerated
+    const size_t base = (size_t)slot * T.node_cap;
+    uint32_t* crow_g = F.crow + base;
+    float* cval_g = F.cval + base;
+    const TreeF X{T, base, ln, lvis, lval, lpri, lmeta, lfc};
+    const bool quirks = P.quirks != 0;
+    // ---- the record the game carries from launch to launch ----
+    const uint32_t seg = G.n == 1 ? 0u : S.seg[slot];
+    const uint32_t seg_first = G.first_slot[seg], seg_end = G.end_slot[seg];
+    const unsigned long long seed = G.seed[seg];
+    const uint32_t gid = S.game_id[slot], rnd = S.round[slot];
+    const float rv0 = S.root_value0[seg];
+    unsigned long long evals = S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS];
+    uint32_t used = T.used[slot];
+    bool lterm = S.leaf_term[slot] != 0;
+    uint32_t leaf = S.leaf[slot], sel = S.sel[slot], leaf_meta = S.leaf_meta[slot];
+    float sel_value = S.sel_value[slot];
+    uint32_t plen = S.path_len[slot];
+    uint32_t pnode = S.path[(size_t)slot * kPathCap + lane];
+    uint32_t cn[SC_COUNT];
+    load_counters(S, slot, cn);
+    const BgState rs = load_state(&T.state[base]);
+    const int root_player = st_player(rs);
+    // Q14's count of stale INITIAL slots matters to the batch's first slot for iterations before every game of the batch has had a real
+    // selection: `fsel` = the latest first selection in the batch as the previous launches left it (a conservative bound: later is safe)
+    uint32_t fsel = 0;
+    if (A.q == 0) { if (lane == 0) F.first_sel[slot] = sel == kNone ? kNone : 0u; }
+    if (quirks && slot == seg_first) {
+        uint32_t m = 0;
+        for (uint32_t g = seg_first + (uint32_t)lane; g < seg_end; g += 64) {
+            const uint32_t f = A.q == 0 ? (S.sel[g] == kNone ? kNone : 0u) : F.first_sel[g];
+            m = f == kNone ? 0x7fffffffu : (f > m ? f : m);
+            if (f == kNone) break;
+        }
+        fsel = (uint32_t)wave_allmax_i32((int)m);
+    }
+    // ---- the tree's statistics into LDS; the rows the previous launch evaluated for this game on top ----
+    const uint32_t nl = used < ln ? used : ln;
+    for (uint32_t i = lane; i < nl; i += 64) {
+        lvis[i] = T.visits[base + i]; lval[i] = T.value[base + i]; lpri[i] = T.prior[base + i];
+        lmeta[i] = T.meta[base + i]; lfc[i] = T.first_child[base + i];
+        lcrow[i] = crow_g[i]; lcval[i] = cval_g[i];
+    }
+    __syncthreads();
+    if (A.q > 0) {
+        const uint32_t pq = A.q - 1, off = F.grant_off[slot], cnt = F.grant_cnt[slot];
+        const size_t rb = (size_t)(pq % F.ring) * F.rows;
+        for (uint32_t r = lane; r < cnt; r += 64) {
+            const uint32_t row = off + r;
+            const uint32_t node = F.rows_idx[rb + row] - (uint32_t)base;
+            const float* h = F.hv + (rb + row) * 72;
+            float dot = 0.0f;
+            for (int i = 0; i < 72; ++i) dot += h[i] * S.wv[i];
+            const float cv = tanhf(dot + S.wv[72]);
+            const uint32_t id = ((pq << kFreeRowBits) | row) + 1u;
+            cval_g[node] = cv; crow_g[node] = id;
+            if (node < ln) { lcval[node] = cv; lcrow[node] = id; }
+        }
+        cn[SC_NN_ROWS] += cnt;
+        __syncthreads();
+    }
+    // a ring row is there while no later launch has reused its place: launch lq's rows until launch lq + ring is evaluated
+    auto at_hand = [&](uint32_t cr) { return cr != 0u && ((cr - 1u) >> kFreeRowBits) + F.ring >= A.q; };
+    auto crow_of = [&](uint32_t i) { return i < ln ? lcrow[i] : crow_g[i]; };
+    // the least progress of the batch's games, as published (own included)
+    auto batch_progress = [&]() {
+        int m = 0x7fffffff;
+        for (uint32_t g = seg_first + (uint32_t)lane; g < seg_end; g += 64) { const int v = (int)free_load(&F.prog[g]); m = v < m ? v : m; }
+        return (uint32_t)(-wave_allmax_i32(-m));
+    };
+    BgState lst = load_state(&S.eval_states[slot]);             // the selected leaf's state
+    bool have = false, stalled = false;
+    uint32_t minprog = 0;                                       // a lower bound of the batch's progress (every game has published iteration 0's selection)
+    for (;;) {
+        const uint32_t cr = lterm ? 0u : crow_of(leaf);
+        have = lterm || at_hand(cr);
+        if (!have) break;
+        // ---- the flag words of this iteration, where the game needs them ----
+        uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
+        const bool need_cnt = quirks && slot == seg_first && it < fsel;
+        const bool need_any = lterm && (quirks || slot == seg_first);
+        uint2 ifl = make_uint2(1u, 0u);
+        if (need_any || need_cnt) {
+            bool fin = false;
+            for (int spin = 0; spin < kFreeSpin; ++spin) {
+                if (!need_cnt && free_load(&iflag[0]) != 0u) { ifl.x = 1u; fin = true; break; }
+                if (minprog < it) minprog = batch_progress();
+                if (minprog >= it) {                            // everybody has published this iteration's selection: the words are final
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    ifl.x = free_load(&iflag[0]); ifl.y = free_load(&iflag[1]);
+                    fin = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!fin) { stalled = true; break; }
+        }
+        const NetRowLoaded pre = [&] {
+            NetRowLoaded p;
+            const size_t ring = lterm ? 0u : (size_t)(((cr - 1u) >> kFreeRowBits) % F.ring) * F.rows + ((cr - 1u) & ((1u << kFreeRowBits) - 1u));
+            p.vh = value_head_load(F.hv + ring * 72, S.wv, lane);
+            softmax_load(F.logits + ring * 1352, lane, p.lg);
+            return p;
+        }();
+        // ================= iteration `it` (expand_body<false, 0>'s operations, in its order) =================
+        const bool active = ifl.x != 0u;
+        float v = 0.0f;
+        bool do_expand = !lterm, do_backprop = true;
+        if (active) {
+            if (slot == seg_first) evals += (unsigned long long)(seg_end - seg_first);
+            if (lterm) {
+                do_expand = false; do_backprop = false;
+                if (quirks && sel != kNone) {                   // the stale slot is backpropagated with its own value again (Q14)
+                    if (plen) { if ((uint32_t)lane < plen) X.add(pnode, sel_value); }
+                    else if (lane == 0) { for (uint32_t i = sel; i != kNone; i = T.parent[base + i]) X.add(i, sel_value); }
+                }
+            } else {
+                v = value_head_eval(pre.vh, lane);
+                sel_value = v;
+            }
+            const uint32_t m0 = lterm ? 0u : leaf_meta;
+            if (do_expand && !(m0 & kDrained)) {
+                int k = bg_legal_plays_wave(lst, &ws, lane, S.overflow);
+                if (k > kMaxPlays) { if (lane == 0) atomicOr(S.overflow, 1u); k = 0; }
+                const int r0 = st_roll(lst, 0), r1 = st_roll(lst, 1);
+                float smM, smInv;
+                softmax_reduce(pre.lg, lane, smM, smInv);
+#pragma unroll
+                for (int q = 0; q < 22; ++q) lgs[lane + 64 * q] = pre.lg[q];
+                __syncthreads();
+                for (int j = lane; j < k; j += 64) {
+                    const uint32_t cd = bg_encode_dev(r0, r1, ws.play[j]);
+                    raw[j] = softmax_prob(lgs[cd], smM, smInv); code[j] = (uint16_t)cd;
+                }
+                __syncthreads();
+                float pr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[r] = lane + 64 * r < k ? raw[lane + 64 * r] : 0.0f;
+                float sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = k - 64 * r < 64 ? k - 64 * r : 64;                    // uniform
+                    for (int j = 0; j < kr; ++j) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[r]), j));
+                }
+                const uint32_t first = used;
+                if (first + (uint32_t)k > T.node_cap) {
+                    if (lane == 0) atomicOr(S.overflow, 2u);
+                } else {
+                    const uint32_t e = it + 1u;
+                    for (int j = lane; j < k; j += 64) {
+                        const uint32_t cl = first + (uint32_t)j;
+                        const size_t ci = base + cl;
+                        BgState cs = lst;
+                        int d0, d1;
+                        draw_dice(seed, gid, rnd, e, (uint32_t)j, d0, d1);      // child dice frozen at creation (Q9), keyed by the GAME's iteration
+                        bg_apply_dev(cs, ws.play[j], d0, d1);
+                        store_state(&T.state[ci], cs);
+                        const float prj = raw[j] / sum;
+                        const uint32_t cm = (uint32_t)code[j] | meta_terminal_bits(cs);
+                        T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = prj;
+                        T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = cm;
+                        crow_g[cl] = 0u;                                         // (crow is zeroed per move-step; kept explicit: a node is born without an evaluation)
+                        if (cl < ln) { lvis[cl] = 0.0f; lval[cl] = 0.0f; lpri[cl] = prj; lmeta[cl] = cm; lfc[cl] = 0; lcrow[cl] = 0; lcval[cl] = 0.0f; }
+                    }
+                    const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & kMetaKeep);
+                    if (lane == 0) X.set_header(leaf, nmeta, first);
+                    used = first + (uint32_t)k;
+                    cn[SC_EXPANSIONS] += 1; cn[SC_CHILDREN] += (uint32_t)k;
+                    if ((uint32_t)k > cn[SC_MAX_CHILDREN]) cn[SC_MAX_CHILDREN] = (uint32_t)k;
+                }
+                __syncthreads();
+            }
+            if (do_backprop) {
+                if (plen) { if ((uint32_t)lane < plen) X.add(pnode, v); }
+                else if (lane == 0) { for (uint32_t i = leaf; i != kNone; i = T.parent[base + i]) X.add(i, v); }
+            }
+            if (quirks && slot == seg_first && ifl.y != 0u && lane == 0) {
+                // slots still holding the initial 0 index re-backpropagate node 0 = this root with the NN value of its state (Q14)
+                float rvis = X.vis(0), rval = X.val(0);
+                for (uint32_t i = 0; i < ifl.y; ++i) { rvis += 1.0f; rval += rv0; }
+                if (ln > 0) { lvis[0] = rvis; lval[0] = rval; }
+                T.visits[base] = rvis; T.value[base] = rval;
+            }
+            __syncthreads();
+        }
+        // ================= selection for iteration it + 1 (select_slot on the LDS copy), published for the other games =================
+        if (it + 1 < F.iterations) {
+            uint32_t* nflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it + 1);
+            uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone;
+            uint32_t mt = X.meta(0), fcn = X.fc(0);
+            float nvis = X.vis(0);
+            for (;;) {
+                const uint32_t k = meta_nch(mt);
+                if (k == 0) break;
+                const float sq = sqrtf(nvis);
+                Best b{0.0f, -1};
+                int lastnan = -1;
+                for (uint32_t j = lane; j < k; j += 64) {
+                    const uint32_t ci = fcn + j;
+                    const float vis = X.vis(ci), val = X.val(ci), pr = X.pri(ci);
+                    const float q = vis == 0.0f ? 0.0f : val / vis;
+                    const float t = sq / (vis + 1.0f);
+                    const float u = c * t;
+                    const float w = u * pr;
+                    const float sc_ = q + w;
+                    if (sc_ != sc_) lastnan = (int)j;
+                    else if (b.j < 0 || !(b.s > sc_)) { b.s = sc_; b.j = (int)j; }
+                }
+                lastnan = wave_allmax_i32(lastnan);
+                if (lastnan >= 0) {                             // the sequential fold restarts after a NaN: only children after the last NaN compete
+                    b.s = 0.0f; b.j = -1;
+                    for (uint32_t j = lane; j < k; j += 64) {
+                        if ((int)j <= lastnan) continue;
+                        const uint32_t ci = fcn + j;
+                        const float vis = X.vis(ci), val = X.val(ci), pr = X.pri(ci);
+                        const float q = vis == 0.0f ? 0.0f : val / vis;
+                        const float t = sq / (vis + 1.0f);
+                        const float u = c * t;
+                        const float w = u * pr;
+                        const float sc_ = q + w;
+                        if (b.j < 0 || !(b.s > sc_)) { b.s = sc_; b.j = (int)j; }
+                    }
+                }
+                b = wave_best(b);
+                const int chosen = b.j >= 0 ? b.j : lastnan;
+                node = fcn + (uint32_t)chosen;
+                ++depth;
+                if ((uint32_t)lane == depth) mine = node;
+                mt = X.meta(node); fcn = X.fc(node); nvis = X.vis(node);
+            }
+            const uint32_t npl = depth < S.path_cap ? depth + 1u : 0u;
+            cn[SC_SELECTIONS] += 1; cn[SC_DEPTH_SUM] += depth;
+            if (mt & kMetaTerminal) {                           // a finished game: +-1 for the ROOT's player (alpha_mcts.rs:157-163)
+                const float tv = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
+                if (npl) { if ((uint32_t)lane < npl) X.add(mine, tv); }
+                else if (lane == 0) { for (uint32_t i = node; i != kNone; i = T.parent[base + i]) X.add(i, tv); }
+                cn[SC_TERMINAL] += 1;
+                lterm = true;
+                if (lane == 0 && quirks && sel == kNone) atomicAdd(&nflag[1], 1u);
+            } else {
+                lterm = false; leaf = node; leaf_meta = mt; plen = npl; pnode = mine;
+                if (lane == 0) {
+                    atomicOr(&nflag[0], 1u);
+                    if (sel == kNone) F.first_sel[slot] = it + 1u;
+                }
+                sel = node;
+                lst = load_state(&T.state[base + node]);
+            }
+        }
+        ++it;
+        __syncthreads();
+        // the flags before the progress: whoever reads `it` here finds this game's words of iteration `it` in place
+        if (lane == 0) { __threadfence(); atomicExch(&F.prog[slot], it); }
+        if (it >= F.iterations) break;
+    }
+    // ---- the record for the next launch (and for whoever reads the slot after the search) ----
+    if (lane == 0) {
+        S.leaf_term[slot] = lterm ? 1 : 0; S.leaf[slot] = leaf; S.sel[slot] = sel; S.leaf_meta[slot] = leaf_meta;
+        S.sel_value[slot] = sel_value; S.path_len[slot] = (uint8_t)plen;
+        T.used[slot] = used;
+        if (slot == seg_first) S.counters[(size_t)seg * CNT_COUNT + CNT_NN_EVALS] = evals;
+        store_state(&S.eval_states[slot], lst);
+    }
+    if ((uint32_t)lane < plen) S.path[(size_t)slot * kPathCap + lane] = pnode;
+    const bool done = it >= F.iterations;
+    uint32_t nw = 0;
+    const bool dem = !done && !stalled && !have;
+    if (!done) {
+        // ---- the wishes for the next launch: the leaf the game waits for, then the unexpanded, unevaluated nodes that virtual descents --
+        // the search's own selection rule run ahead on a scratch copy of visits / value; an unknown evaluation counts as 0, a known one as
+        // its value, a finished game as +-1 for the root's player -- end on, in the order they are found (= the order the search will want them) ----
+        uint32_t* wl = F.wish + (size_t)slot * kFreeWish;
+        if (dem) { if (lane == 0) wl[0] = leaf; nw = 1; }
+        const uint32_t want = F.cand_max < kFreeWish - 1u ? F.cand_max : kFreeWish - 1u;
+        uint32_t ncand = 0;
+        if (want > 0 && F.rollout_steps > 0) {
+            const uint32_t nu = used < ln ? used : ln;
+            for (uint32_t i = lane; i < nu; i += 64) { vvis[i] = lvis[i]; vval[i] = lval[i]; }
+            __syncthreads();
+            const uint32_t demanded = dem ? leaf : kNone;
+            uint32_t fruitless = 0;
+            for (uint32_t step = 0; step < F.rollout_steps && ncand < want && fruitless < 8; ++step) {
+                uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
+                for (;;) {
+                    mt = X.meta(node);
+                    const uint32_t k = meta_nch(mt);
+                    if (k == 0) break;
+                    const uint32_t fcn = X.fc(node);
+                    const float sq = sqrtf(node < nu ? vvis[node] : T.visits[base + node]);
+                    Best b{0.0f, -1};
+                    for (uint32_t j = lane; j < k; j += 64) {
+                        const uint32_t ci = fcn + j;
+                        const float vis = ci < nu ? vvis[ci] : T.visits[base + ci], val = ci < nu ? vval[ci] : T.value[base + ci];
+                        const float q = vis == 0.0f ? 0.0f : val / vis;
+                        const float sc_ = q + (c * (sq / (vis + 1.0f))) * X.pri(ci);
+                        if (sc_ == sc_ && (b.j < 0 || !(b.s > sc_))) { b.s = sc_; b.j = (int)j; }
+                    }
+                    b = wave_best(b);
+                    node = fcn + (uint32_t)(b.j >= 0 ? b.j : (int)k - 1);
+                    ++depth;
+                    if ((uint32_t)lane == depth) mine = node;
+                    if (depth >= 63) break;
+                }
+                const uint32_t cr = crow_of(node);
+                float x = 0.0f;
+                bool fresh = false;
+                if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
+                else if (at_hand(cr)) x = node < ln ? lcval[node] : cval_g[node];
+                else if (!(mt & kDrained) && node != demanded) fresh = __ballot((uint32_t)lane < ncand && cand[lane] == node) == 0ull;
+                if (fresh) { if (lane == 0) { cand[ncand] = node; wl[nw + ncand] = node; } ++ncand; fruitless = 0; } else ++fruitless;
+                if ((uint32_t)lane <= depth && mine < nu) { vvis[mine] += 1.0f; vval[mine] += x; }
+                __syncthreads();
+            }
+        }
+        nw += ncand;
+    }
+    if (lane == 0) {
+        F.wish_n[slot] = nw | (it << 8) | (dem ? 0x80000000u : 0u);
+        store_counters(S, slot, cn);
+    }
+}
+
+// The rows of launch q: every demanded leaf, then the other wishes rank by rank (every game's first candidate, then every game's second ...)
+// until the launch is full; a game's rows are contiguous (k_free takes them in by grant_off / grant_cnt).  One workgroup, one thread per game,
+// the games in an order that turns with the launch (the rank that does not fit whole goes to the games that come first).
+__global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t node_cap, uint32_t q) {
+    __shared__ uint32_t hist[kFreeWish + 1];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_full, s_rem, s_dem, s_undone;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (F.state[0] != 0u) return;                               // the search was complete a round ago: n_rows[q] stays 0
+    if (tid <= (int)kFreeWish) hist[tid] = 0;
+    if (tid == 0) { s_dem = 0; s_undone = 0; }
+    __syncthreads();
+    const uint32_t rot = (q * 131u) % n;
+    const uint32_t g = (uint32_t)tid < n ? ((uint32_t)tid + rot) % n : 0u;
+    const uint32_t w = (uint32_t)tid < n ? F.wish_n[g] : ((F.iterations) << 8);
+    const uint32_t cnt = w & 0xffu, dem = w >> 31, spec = cnt - dem;
+    const bool undone = ((w >> 8) & 0x7fffffu) < F.iterations;
+    if ((uint32_t)tid < n) { atomicAdd(&hist[spec], 1u); if (dem) atomicAdd(&s_dem, 1u); if (undone) atomicOr(&s_undone, 1u); }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t room = F.rows > s_dem ? F.rows - s_dem : 0u;
+        uint32_t full = 0, used_rows = 0, at_least = 0;
+        // games that wish for at least r rows, r = kFreeWish ... 1, turned into "ranks that fit whole"
+        uint32_t ge[kFreeWish + 2];
+        ge[kFreeWish + 1] = 0;
+        for (int r = (int)kFreeWish; r >= 0; --r) ge[r] = ge[r + 1] + hist[r];
+        for (uint32_t r = 1; r <= kFreeWish; ++r) {
+            at_least = ge[r];
+            if (at_least == 0 || used_rows + at_least > room) break;
+            used_rows += at_least; full = r;
+        }
+        s_full = full; s_rem = room - used_rows;
+    }
+    __syncthreads();
+    const uint32_t full = s_full, rem = s_rem;
+    // the next rank, as far as the rows go: the first `rem` games (in this launch's order) that wish for more than `full`
+    const int more = ((uint32_t)tid < n && spec > full) ? 1 : 0;
+    int inc = wave_inclusive_scan_i32(more);
+    if (lane == 63) wsum[wave] = (uint32_t)inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int v = 0; v < wave; ++v) before += wsum[v];
+    const uint32_t my_rank = before + (uint32_t)(inc - more);
+    __syncthreads();
+    const uint32_t grant = (uint32_t)tid < n ? dem + (spec < full ? spec : full) + ((more && my_rank < rem) ? 1u : 0u) : 0u;
+    inc = wave_inclusive_scan_i32((int)grant);
+    if (lane == 63) wsum[wave] = (uint32_t)inc;
+    __syncthreads();
+    before = 0;
+    uint32_t total = 0;
+    for (int v = 0; v < 16; ++v) { if (v < wave) before += wsum[v]; total += wsum[v]; }
+    const uint32_t off = before + (uint32_t)inc - grant;
+    if ((uint32_t)tid < n) {
+        const uint32_t fit = off >= F.rows ? 0u : (grant < F.rows - off ? grant : F.rows - off);     // (the host never asks for fewer rows than games: no demanded leaf is cut)
+        F.grant_off[g] = off; F.grant_cnt[g] = fit;
+        uint32_t* out = F.rows_idx + (size_t)(q % F.ring) * F.rows + off;
+        const uint32_t* wl = F.wish + (size_t)g * kFreeWish;
+        for (uint32_t j = 0; j < fit; ++j) out[j] = g * node_cap + wl[j];
+    }
+    if (tid == 0) {
+        if (total > F.rows) total = F.rows;
+        F.n_rows[q] = total;
+        const uint32_t all_done = s_undone ? 0u : 1u;
+        F.state[0] = all_done;
+        if (total) { F.state[1] += 1u; F.state[2] += total - s_dem; }
+        F.host[0] = all_done; F.host[1] = q;
+        __threadfence_system();
+    }
+}
+
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
 __global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
     __shared__ unsigned long long part[SC_COUNT][4];
@@ -1445,6 +1892,26 @@ void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
         attr_set[dev & 15] = true;
     }
     hipLaunchKernelGGL(k_tail, dim3(n <= 32 ? 8 * n : n), dim3(64), sizeof(TailLds), st, T, S, G, n, P, c, TailArgs{L, q});
+}
+uint32_t free_lds_nodes_for(uint32_t n, uint32_t cus) {
+    // the workgroups (one per game) that share a CU split its 160 KB of LDS: what a game's scratch leaves goes to its tree
+    const uint32_t per_cu = (n + cus - 1) / (cus ? cus : 1u);
+    const size_t budget = (size_t)160 * 1024 / (per_cu ? per_cu : 1u);
+    const size_t fixed = free_lds_bytes(0);
+    if (budget <= fixed + 64 * 36) return 64;
+    uint32_t ln = (uint32_t)((budget - fixed) / 36) / 64 * 64;
+    return ln > kTailLdsNodes ? kTailLdsNodes : ln;
+}
+void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Free& F, uint32_t q) {
+    static bool attr_set[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 15]) {
+        (void)hipFuncSetAttribute((const void*)k_free, hipFuncAttributeMaxDynamicSharedMemorySize, (int)free_lds_bytes(kTailLdsNodes));
+        attr_set[dev & 15] = true;
+    }
+    hipLaunchKernelGGL(k_free, dim3(n), dim3(64), free_lds_bytes(F.lds_nodes), st, T, S, G, n, P, c, FreeArgs{F, q});
+    hipLaunchKernelGGL(k_free_pack, dim3(1), dim3(1024), 0, st, F, n, T.node_cap, q);
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

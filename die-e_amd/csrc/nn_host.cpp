@@ -571,6 +571,41 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
     return ok;
 }
 
+// The free-running search (search_types.h, Free): one evaluation of up to rows_upper rows whose states are gathered from the tree arena by
+// index (`rows_idx[row]` = slot * node_cap + node) and whose number k_free_pack wrote to *n_rows_dev -- the fused tower's compacted-batch
+// launches (launch_tower_compact: one pass of the chip for 929 ... 1024 rows, the part-filled instantiation or the pair tower below) + the
+// policy FC, outputs straight into the caller's ring rows.  Every launch is of the fused 16x16x32 family: a row's bits are those of a plain
+// evaluation of more than 128 boards, whichever launch computes it.
+bool nn_free_available(Engine& e, int n) {
+    if (!e.net || !e.net->loaded) return false;
+    const NetWeights& W = *e.net;
+    return W.fused_heads && W.cluster_init && W.tower_geometry_for(n) >= 2;       // the plain evaluations of these n games are of the fused family too
+}
+void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band) {
+    NetWeights& W = *e.net;
+    nn_reserve(e, rows_upper);
+    hipStream_t st = e.stream;
+    const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
+    const bool sample = W.sample_every > 0 && (W.forward_count++ % W.sample_every) == 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (sample) {
+        W.rows_log.ensure(kRowsLog);
+        HIPCHK(hipMemcpyAsync(W.rows_log.p + seq, n_rows_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st));
+    }
+    uint16_t* pex = pair_exchange(e);
+    if (pex) W.cluster_used = true;                                 // (the pair tower's hand-overs report through the starved-hand-over bit)
+    launch_tower_compact(st, W.wtower16.p, W.btower.p, rows_upper, arena_states, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
+                         W.hp.p, hv_out, rows_idx, n_rows_dev, pex, e.flags_dev.p);
+    W.last_dispatch.clear();
+    W.last_dispatch.push_back({1, -1, rows_upper});
+    if (sample) {
+        HIPCHK(hipEventRecord(ev1, st));
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, boards_band});     // flops per ROW; a launch without rows is dropped at the harvest
+    }
+    fc_launch(e, W.hp.p, logits_out, rows_upper, n_rows_dev);
+}
+
 // ---- development probes: which kernel a (family, geometry) is, and the dispatch of a plain evaluation by its board count ----
 const char* nn_kernel_name(int family, int geometry) {
     switch (family) {

@@ -114,6 +114,8 @@ struct DispatchBand { int boards_min, boards_max, family, geometry; };
 std::vector<DispatchBand> nn_dispatch_bands(Engine& e, int upto);
 bool nn_tail_available(Engine& e, int G_upper, int n);
 bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band);
+bool nn_free_available(Engine& e, int n);
+void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band);
 bool nn_cluster_used(Engine& e);
 void nn_disable_cluster(Engine& e);
 void nn_reset_cluster(Engine& e);

@@ -44,6 +44,13 @@ struct SearchBufs {
     uint32_t tl_launches = 0, tl_node_cap = 0, tl_rows_cap = 0;
     uint32_t tl_prev_need = 0;                                 // tower launches the previous move-step's search needed (sizes the first chunk)
     uint64_t tl_iterations = 0, tl_launched = 0, tl_with_rows = 0, tl_spec_rows = 0, tl_syncs = 0;      // this call's totals
+    // the free-running search (search_types.h, Free)
+    DevBuf<uint32_t> fr_crow, fr_rows_idx, fr_words, fr_slots, fr_wish;      // fr_words = n_rows[launches] ++ state[4]; fr_slots = grant_off ++ grant_cnt ++ wish_n ++ prog ++ first_sel, [slots] each
+    DevBuf<float> fr_cval, fr_logits, fr_hv;
+    uint32_t* fr_host = nullptr;                                // pinned, [2]
+    uint32_t fr_launches = 0, fr_ring = 0, fr_rows = 0, fr_slot_cap = 0, fr_node_cap = 0;
+    uint32_t fr_prev_need = 0;
+    int cus = 0;                                                // compute units of the device (how many games' workgroups share one)
     // batches ("segments") in flight
     DevBuf<unsigned long long> seg_seed;
     DevBuf<uint32_t> seg_first_id, seg_game0, seg_slots;      // seg_slots = first_slot[kMaxSegments] ++ end_slot[kMaxSegments]
@@ -70,6 +77,7 @@ struct SearchBufs {
         if (copy) (void)hipStreamDestroy(copy);
         for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
         if (tl_host) (void)hipHostFree(tl_host);
+        if (fr_host) (void)hipHostFree(fr_host);
         if (noise_host) (void)hipHostFree(noise_host);
         if (live_host) (void)hipHostFree(live_host);
     }
@@ -334,6 +342,84 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     B.tl_iterations += cfg.iterations; B.tl_launched += sent; B.tl_with_rows += words[2]; B.tl_spec_rows += words[3];
 }
 
+// ---- the free-running search (search_types.h, Free) -----------------------------------------------------------------------------
+// rows of a launch: up to 512 live games the 4-board pair tower's 512 rows (~300 us), beyond one pass of the chip (1024 rows, ~577 us); a
+// game needs 0.91 rows per iteration and the virtual descents see about one iteration ahead, so more than ~2 rows per game and launch are not used
+uint32_t free_rows_for(const Engine& e, uint32_t n) { return n >= e.opt.free_rows1024_from ? 1024u : 512u; }
+bool free_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
+    if (e.opt.free_eval == 0 || cfg.iterations < 1 || cfg.iterations >= (1u << 22)) return false;
+    if (n < e.opt.free_min_games || n > std::min<uint32_t>(e.opt.free_max_games, kFreeMaxSlots)) return false;
+    if (free_rows_for(e, n) < n) return false;                    // every live game's demanded leaf must fit the launch
+    return nn_free_available(e, (int)n);
+}
+
+Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
+    const uint32_t launches = cfg.iterations + 2, rows = free_rows_for(e, n);
+    // the ring holds the rows of the last `ring` launches: a whole search at iterations = 100, option free_ring launches beyond
+    const uint32_t ring = std::min<uint32_t>(launches, std::max<uint32_t>(e.opt.free_ring, 4u));
+    if (n > B.fr_slot_cap || B.node_cap > B.fr_node_cap) {
+        const uint32_t sc = std::max(n, B.fr_slot_cap), nc = std::max(B.node_cap, B.fr_node_cap);
+        B.fr_crow.ensure((size_t)sc * nc); B.fr_cval.ensure((size_t)sc * nc);
+        B.fr_slots.ensure((size_t)5 * sc); B.fr_wish.ensure((size_t)sc * kFreeWish);
+        B.fr_slot_cap = sc; B.fr_node_cap = nc;
+    }
+    if (ring > B.fr_ring || rows > B.fr_rows) {
+        const uint32_t W = std::max(ring, B.fr_ring), R = std::max(rows, B.fr_rows);
+        B.fr_rows_idx.ensure((size_t)W * R); B.fr_logits.ensure((size_t)W * R * 1352); B.fr_hv.ensure((size_t)W * R * 72);
+        B.fr_ring = W; B.fr_rows = R;
+    }
+    if (launches > B.fr_launches) { B.fr_words.ensure((size_t)launches + 4); B.fr_launches = launches; }
+    if (!B.fr_host) { HIPCHK(hipHostMalloc((void**)&B.fr_host, sizeof(uint32_t) * 2)); memset(B.fr_host, 0, sizeof(uint32_t) * 2); }
+    if (!B.cus) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, e.device)); B.cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    uint32_t* sl = B.fr_slots.p;
+    const uint32_t sc = B.fr_slot_cap;
+    return Free{B.fr_crow.p, B.fr_cval.p, B.fr_rows_idx.p, B.fr_logits.p, B.fr_hv.p, B.fr_words.p, sl, sl + sc, B.fr_wish.p, sl + 2 * (size_t)sc, sl + 3 * (size_t)sc,
+                sl + 4 * (size_t)sc, B.fr_words.p + B.fr_launches, B.fr_host, launches, cfg.iterations, rows, ring,
+                std::min<uint32_t>(free_lds_nodes_for(n, (uint32_t)B.cus), std::max<uint32_t>(e.opt.free_lds_nodes, 64u)), e.opt.free_rollout_steps, e.opt.free_cand_max};
+}
+
+// The iterations of one move-step's search for 257 ... 928 live games, behind the root expansion (k_expand has selected every game's leaf
+// for iteration 0): round 0 = { k_free, k_free_pack }, then rounds { tower launch q over the rows granted, k_free, k_free_pack }.  The game
+// furthest behind completes an iteration in every round, so `iterations` + 1 rounds always suffice -- and about 0.91 * n / rows of that do.
+// Rounds sent ahead of a search that is complete return at once, so they go out in chunks, the host looking at the done word in between.
+void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& G, const diee_mcts_cfg& cfg, const SearchParams& P) {
+    SearchBufs& B = *e.search;
+    const Free F = free_view(e, B, cfg, n);
+    hipStream_t st = e.stream;
+    // crow of the slots in use (the trees are rebuilt every move-step), the row counts and state words, the per-slot progress (first_sel is
+    // written by round 0)
+    HIPCHK(hipMemsetAsync(F.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
+    HIPCHK(hipMemsetAsync(B.fr_words.p, 0, sizeof(uint32_t) * ((size_t)B.fr_launches + 4), st));
+    HIPCHK(hipMemsetAsync(B.fr_slots.p, 0, sizeof(uint32_t) * (size_t)5 * B.fr_slot_cap, st));
+    B.fr_host[0] = 0; B.fr_host[1] = 0xFFFFFFFFu;
+    launch_free(st, T, S, G, n, P, cfg.c, F, 0);
+    uint32_t q = 0, sent = 0;
+    uint32_t chunk = B.fr_prev_need ? B.fr_prev_need + 2 : std::max<uint32_t>(8u, (uint32_t)((double)cfg.iterations * n / F.rows) + 4u);
+    bool done = false;
+    while (!done && q <= cfg.iterations) {
+        const uint32_t end = std::min<uint32_t>(cfg.iterations + 1, q + std::max<uint32_t>(chunk, 1u));
+        for (; q < end; ++q, ++sent) {
+            const size_t rb = (size_t)(q % F.ring) * F.rows;
+            nn_forward_free(e, T.state, F.rows_idx + rb, F.n_rows + q, (int)F.rows, F.hv + rb * 72, F.logits + rb * 1352, (int)n);
+            launch_free(st, T, S, G, n, P, cfg.c, F, q + 1);
+        }
+        HIPCHK(hipGetLastError());
+        e.sync();
+        ++B.tl_syncs;
+        done = B.fr_host[0] != 0;
+        chunk = 4;
+    }
+    uint32_t words[4] = {0, 0, 0, 0};
+    e.d2h(words, F.state, 4);
+    e.sync();
+    if (!done) throw EngineError(DIEE_ERR_HIP, "free-running search: the iterations did not complete");
+    if (e.opt.trace_steps)
+        fprintf(stderr, "[diee] free-running: %u games, %u iterations on %u launches with rows of <= %u (%u rounds sent), %u speculative rows, %u nodes in LDS\n",
+                n, cfg.iterations, words[1], F.rows, sent, words[2], F.lds_nodes);
+    B.fr_prev_need = words[1];
+    B.tl_iterations += cfg.iterations; B.tl_launched += sent; B.tl_with_rows += words[1]; B.tl_spec_rows += words[2];
+}
+
 // alpha_mcts_parallel on the n slots already loaded into B.roots / game_id / round / seg (segment table uploaded, the
 // Dirichlet samples of this move-step in pinned buffer `buf`).  Above the tail's reach it enqueues only; a tail search (tail_run) looks at
 // its done word between chunks of launches, i.e. synchronises a few times per move-step.
@@ -375,6 +461,13 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     if (tail_possible(e, n, cfg)) {
         S.slot_row = nullptr;
         tail_run(e, n, T, S, G, cfg, P);
+        launch_reduce_counters(st, S, G);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+    if (free_possible(e, n, cfg)) {
+        S.slot_row = nullptr;
+        free_run(e, n, T, S, G, cfg, P);
         launch_reduce_counters(st, S, G);
         HIPCHK(hipGetLastError());
         return;
@@ -479,7 +572,7 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     sync();
     const int se = net->sample_every; net->sample_every = 0;
     draw_noise(B, 0, one, step, cfg->dir_alpha);
-    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0;
+    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0; B.fr_prev_need = 0;
     mcts_run(*this, n, 1, *cfg, 0, flags);
     if (cluster_starved(*this)) {                                   // repeat on the per-layer kernels
         HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
@@ -613,7 +706,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     };
 
     upload_segments(*this, bt);
-    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0;
+    B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0; B.fr_prev_need = 0;
     nn_reset_timing(*this);
     launch_init_games(stream, Gm, G, n_games);
     draw_noise(B, 0, bt, 0, cfg->dir_alpha);

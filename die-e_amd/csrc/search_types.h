@@ -153,6 +153,43 @@ struct Tail {
     uint32_t extra_rows;    // candidates a game may find beyond its share of a full launch's rows: they take what other games left free (0: off)
 };
 
+// ---- free-running search (round 6): 257 ... 928 live games ---------------------------------------------------------------------------
+// Above the tail's reach every MCTS iteration used to cost one network launch sized by the live games -- 300 us for <= 512 boards,
+// ~480 ... 520 us for 513 ... 928, 577 us for a full pass of the chip: the rows of a part-empty launch cost up to twice a full one's.  The
+// reference couples the games of a call only through `node_selected` (alpha_mcts.rs:151,170) and the stale slots (:142,192-200), so
+// every game keeps its OWN iteration counter: a round = one launch of up to `rows` rows (the fused family, rows gathered from the tree
+// arena by index: launch_tower_compact) + k_free, where each game takes in its rows, runs iterations for as long as its selected leaf is
+// a finished game or has its evaluation (and the flags it needs are final), then lists its wishes -- the leaf it waits for, then the
+// unexpanded nodes its virtual PUCT descents end on -- and k_free_pack grants them: every demanded leaf, then the wishes rank by rank
+// until the launch is full.  No workgroup ever waits for another one inside a launch (a game that needs a flag another game has not
+// published yet simply stops for this round), so nothing has to be co-resident.  Priced before it was built: tests/tools/free_price.*,
+// profiles/r06a_*.  Results are bit-identical to the lockstep search: the same operations on the same numbers in the same order per game.
+constexpr uint32_t kFreeWish = 24;        // wishes a game may list per round (demanded leaf included)
+constexpr uint32_t kFreeMaxSlots = 1024;  // k_free_pack: one thread per game
+struct Free {
+    uint32_t* crow;         // [slots][node_cap] 1 + launch * rows + row of a node's evaluation (0: none); valid while launch + ring > the current launch
+    float* cval;            // [slots][node_cap] its value (virtual descents only)
+    uint32_t* rows_idx;     // [ring][rows] arena index (slot * node_cap + node) of every row of a launch: the tower gathers its states through it
+    float* logits;          // [ring][rows][1352]
+    float* hv;              // [ring][rows][72]
+    uint32_t* n_rows;       // [launches] rows of launch q
+    uint32_t* grant_off;    // [slots] first row of the slot in the launch planned last ...
+    uint32_t* grant_cnt;    // [slots] ... and how many it got
+    uint32_t* wish;         // [slots][kFreeWish] nodes, most wanted first
+    uint32_t* wish_n;       // [slots] count | 0x80000000 when wish[0] is the demanded leaf | progress << 8 (the packer may favour games behind)
+    uint32_t* prog;         // [slots] the iteration whose selection the game has published = its own iteration counter
+    uint32_t* first_sel;    // [slots] iteration of the game's first real selection (0xFFFFFFFF: none yet): Q14's count matters only before it
+    uint32_t* state;        // [0] all games done, [1] launches that carried rows, [2] rows evaluated on speculation, [3] iterations run
+    uint32_t* host;         // pinned: [0] done, [1] last k_free_pack that finished
+    uint32_t launches;      // iterations + 2
+    uint32_t iterations;
+    uint32_t rows;          // rows of a launch at most (512: pair tower; 1024: one pass of the chip)
+    uint32_t ring;          // launches whose rows stay in the ring
+    uint32_t lds_nodes;     // nodes of a game's tree staged in LDS (by the workgroups that share a CU)
+    uint32_t rollout_steps; // virtual descents per game and round at most
+    uint32_t cand_max;      // candidates a game lists at most (< kFreeWish)
+};
+
 struct SearchParams {
     float dir_eps;
     uint32_t quirks;
