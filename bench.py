@@ -590,7 +590,7 @@ def main(argv=None, engine_factory=None):
             "full_seconds", "full_launches", "full_flops",
             "cluster_seconds", "cluster_launches", "cluster_flops",
             "fragments", "illegal_decodes", "deliver_seconds", "deliver_bytes", "tail_iterations", "tail_launches", "tail_spec_rows"]
-    keys += [f"{n}.{b}" for n in ("band_seconds", "band_launches", "band_flops") for b in range(len(BAND_NAMES))]
+    keys += [f"{n}.{b}" for n in ("band_seconds", "band_launches", "band_flops", "band_flops_demanded") for b in range(len(BAND_NAMES))]
     frags_per_rank = [int(tot.get("fragments", 0))]
     # every rank's own rate over the shared clock window (games it retired / its own time inside the K calls): a straggler shows here
     own_s = sum(step_s)
@@ -709,13 +709,16 @@ def main(argv=None, engine_factory=None):
             dominant = dict({"end_to_end_frac": e2e, "end_to_end_frac_rows_evaluated": e2e_rows, "speculative_row_share": spec_share,
                              "profile_set": f"profiles/{PROFILE_SET}_*"}, **dominant)
             # where a batch's network time goes as it shrinks: every sampled evaluation of this run (each 17th, HIP events on the
-            # engine's stream) binned by the boards of its launch
+            # engine's stream) binned by the live games of its move-step.  `frac` counts the rows the SEARCH asked for (the demanded
+            # leaves of a tail / free-running launch, every row of a plain evaluation), `frac_rows_evaluated` also the speculative ones
             bands = []
             for b, name in enumerate(BAND_NAMES):
                 sec, n, fl = tot.get(f"band_seconds.{b}", 0), tot.get(f"band_launches.{b}", 0), tot.get(f"band_flops.{b}", 0)
+                fld = tot.get(f"band_flops_demanded.{b}", fl)
                 if n:
                     bands.append({"boards": name, "sampled_evaluations": n / world, "share_of_network_time": sec / sampled_total,
-                                  "avg_us": sec / n * 1e6, "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS})
+                                  "avg_us": sec / n * 1e6, "frac": fld / sec / 1e12 / PEAK_BF16_TFLOPS,
+                                  "frac_rows_evaluated": fl / sec / 1e12 / PEAK_BF16_TFLOPS})
             dominant["bands"] = bands
         workload = (f"{preset['name']}: " if not custom else "") + (
             f"backgammon self_play_parallel, num_self_play_batches={args.games} per GPU, "

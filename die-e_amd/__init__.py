@@ -88,7 +88,8 @@ class Stats(C.Structure):
                    ("full_seconds", C.c_double), ("full_launches", C.c_uint64), ("full_flops", C.c_double),
                    ("deliver_seconds", C.c_double), ("deliver_bytes", C.c_uint64),
                    ("band_seconds", C.c_double * 9), ("band_launches", C.c_uint64 * 9), ("band_flops", C.c_double * 9),
-                   ("tail_iterations", C.c_uint64), ("tail_launches", C.c_uint64), ("tail_spec_rows", C.c_uint64)])
+                   ("tail_iterations", C.c_uint64), ("tail_launches", C.c_uint64), ("tail_spec_rows", C.c_uint64),
+                   ("band_flops_demanded", C.c_double * 9)])
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n.startswith("band_") else getattr(self, n)) for n, _ in self._fields_}

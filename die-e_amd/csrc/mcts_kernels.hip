@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
     }
     if (lane == 0) store_counters(S, slot, cn);
     TL_STAMP(3);
+    if (slot == 0 && lane == 0 && !done) L.n_dem[A.q] = misses;
     if (slot == 0 && lane == 0) {
         // (a meeting that timed out in ANY workgroup left 2 in state[1]: it stays -- atomicMax, 0 < 1 < 2 -- and tail_run takes the starved path)
         const uint32_t was = atomicMax(&L.state[1], done ? 1u : 0u);
@@ -1090,7 +1091,11 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
 // then its progress) and polled for a bounded few microseconds; a game that still cannot tell stops for this round -- that changes
 // when things are computed, never what.  The game furthest behind can always go on (everybody has published its iteration), so
 // every launch pair completes at least one iteration of it: `iterations` pairs always suffice.
-constexpr int kFreeSpin = 48;
+// polls of the flag words before a game gives up for the round.  A game that runs ahead of the others through finished-game leaves (they need
+// no evaluation) reaches iterations nobody else has published: the others are waiting for their rows, so polling there only prolongs the
+// launch (48 polls of a 600-game progress scan cost ~150 us per launch on the first build: profiles/r06b_*); it looks once while many games
+// share the launch and polls only where the few games of a batch's end run side by side
+constexpr int kFreeSpinFew = 48, kFreeFewGames = 64;
 constexpr uint32_t kFreeRowBits = 12;                        // crow = ((launch << kFreeRowBits) | row) + 1
 struct FreeArgs { Free F; uint32_t q; };
 __host__ __device__ constexpr size_t free_lds_bytes(uint32_t ln) {
@@ -1218,7 +1223,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         uint2 ifl = make_uint2(1u, 0u);
         if (need_any || need_cnt) {
             bool fin = false;
-            for (int spin = 0; spin < kFreeSpin; ++spin) {
+            const int spins = n <= (uint32_t)kFreeFewGames ? kFreeSpinFew : 1;
+            for (int spin = 0; spin < spins; ++spin) {
                 if (!need_cnt && free_load(&iflag[0]) != 0u) { ifl.x = 1u; fin = true; break; }
                 if (minprog < it) minprog = batch_progress();
                 if (minprog >= it) {                            // everybody has published this iteration's selection: the words are final
@@ -1517,7 +1523,7 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
     }
     if (tid == 0) {
         if (total > F.rows) total = F.rows;
-        F.n_rows[q] = total;
+        F.n_rows[q] = total; F.n_dem[q] = s_dem < total ? s_dem : total;
         const uint32_t all_done = s_undone ? 0u : 1u;
         F.state[0] = all_done;
         if (total) { F.state[1] += 1u; F.state[2] += total - s_dem; }

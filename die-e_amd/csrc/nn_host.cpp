@@ -530,7 +530,8 @@ bool nn_tail_available(Engine& e, int G_upper, int n) {
     };
     return split8(G_upper) && split8(n);
 }
-bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band) {
+bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band,
+                     const uint32_t* n_dem_dev) {
     NetWeights& W = *e.net;
     nn_reserve(e, G_upper);
     const uint32_t seq = (uint32_t)(W.forward_count & (kRowsLog - 1));
@@ -541,6 +542,7 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
         W.rows_log.ensure(kRowsLog);
         HIPCHK(hipMemsetAsync(W.rows_log.p + seq, 0, sizeof(uint32_t), e.stream));
         rows_log = W.rows_log.p + seq;
+        if (n_dem_dev) { W.dem_log.ensure(kRowsLog); HIPCHK(hipMemcpyAsync(W.dem_log.p + seq, n_dem_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, e.stream)); }
         ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, e.stream));
     }
     bool ok;
@@ -565,7 +567,7 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
     if (sample) {
         if (ok) {
             HIPCHK(hipEventRecord(ev1, e.stream));
-            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 2, (int)seq, boards_band});      // flops per ROW; a launch without rows is dropped at the harvest
+            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 2, (int)seq, boards_band, n_dem_dev ? (int)seq : -1});      // flops per ROW; a launch without rows is dropped at the harvest
         } else { W.free_events.push_back(ev0); W.free_events.push_back(ev1); }
     }
     return ok;
@@ -581,7 +583,8 @@ bool nn_free_available(Engine& e, int n) {
     const NetWeights& W = *e.net;
     return W.fused_heads && W.cluster_init && W.tower_geometry_for(n) >= 2;       // the plain evaluations of these n games are of the fused family too
 }
-void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band) {
+void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band,
+                     const uint32_t* n_dem_dev) {
     NetWeights& W = *e.net;
     nn_reserve(e, rows_upper);
     hipStream_t st = e.stream;
@@ -591,6 +594,7 @@ void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_i
     if (sample) {
         W.rows_log.ensure(kRowsLog);
         HIPCHK(hipMemcpyAsync(W.rows_log.p + seq, n_rows_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        if (n_dem_dev) { W.dem_log.ensure(kRowsLog); HIPCHK(hipMemcpyAsync(W.dem_log.p + seq, n_dem_dev, sizeof(uint32_t), hipMemcpyDeviceToDevice, st)); }
         ev0 = W.get_event(); ev1 = W.get_event(); HIPCHK(hipEventRecord(ev0, st));
     }
     uint16_t* pex = pair_exchange(e);
@@ -601,7 +605,7 @@ void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_i
     W.last_dispatch.push_back({1, -1, rows_upper});
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, boards_band});     // flops per ROW; a launch without rows is dropped at the harvest
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, boards_band, n_dem_dev ? (int)seq : -1});     // flops per ROW; a launch without rows is dropped at the harvest
     }
     fc_launch(e, W.hp.p, logits_out, rows_upper, n_rows_dev);
 }
@@ -674,13 +678,20 @@ NetHeads nn_heads(Engine& e, int G) {
 void nn_harvest(Engine& e, diee_stats* stats) {
     if (!e.net) return;
     NetWeights& W = *e.net;
-    std::vector<uint32_t> rows_log;
+    std::vector<uint32_t> rows_log, dem_log;
     for (auto& p : W.pending) if (p.rows_seq >= 0 && rows_log.empty()) {
         rows_log.resize(kRowsLog);
         e.d2h(rows_log.data(), W.rows_log.p, (size_t)kRowsLog); e.sync();
     }
+    for (auto& p : W.pending) if (p.dem_seq >= 0 && dem_log.empty()) {
+        dem_log.resize(kRowsLog);
+        e.d2h(dem_log.data(), W.dem_log.p, (size_t)kRowsLog); e.sync();
+    }
     for (auto& p : W.pending) {
         float ms = 0.f;
+        double flops_dem = p.flops;                                                 // (a plain or compacted evaluation: every row was asked for)
+        if (p.dem_seq >= 0) flops_dem = p.flops * (double)dem_log[(size_t)p.dem_seq];
+        else if (p.rows_seq >= 0) flops_dem = p.flops * (double)rows_log[(size_t)p.rows_seq];
         if (p.rows_seq >= 0) p.flops *= (double)rows_log[(size_t)p.rows_seq];      // compacted batch: flops per row x rows evaluated
         const bool empty = p.rows_seq >= 0 && rows_log[(size_t)p.rows_seq] == 0;   // (a tail launch sent ahead of a search that was complete already)
         if (!empty && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -692,7 +703,7 @@ void nn_harvest(Engine& e, diee_stats* stats) {
             static const int bounds[DIEE_BANDS - 1] = {16, 32, 64, 128, 256, 512, 928, 1024};      // DIEE_BANDS, include/diee.h
             int b = 0;
             while (b < (int)DIEE_BANDS - 1 && p.boards > bounds[b]) ++b;
-            W.band_seconds[b] += ms * 1e-3; W.band_launches[b] += 1; W.band_flops[b] += p.flops;
+            W.band_seconds[b] += ms * 1e-3; W.band_launches[b] += 1; W.band_flops[b] += p.flops; W.band_flops_demanded[b] += flops_dem;
         }
         W.free_events.push_back(p.a); W.free_events.push_back(p.b);
     }
@@ -702,7 +713,7 @@ void nn_harvest(Engine& e, diee_stats* stats) {
         stats->tower_seconds = W.tower_seconds; stats->tower_launches = W.tower_launches; stats->tower_flops = W.tower_flops;
         stats->cluster_seconds = W.cluster_seconds; stats->cluster_launches = W.cluster_launches; stats->cluster_flops = W.cluster_flops;
         stats->full_seconds = W.full_seconds; stats->full_launches = W.full_launches; stats->full_flops = W.full_flops;
-        for (int b = 0; b < (int)DIEE_BANDS; ++b) { stats->band_seconds[b] = W.band_seconds[b]; stats->band_launches[b] = W.band_launches[b]; stats->band_flops[b] = W.band_flops[b]; }
+        for (int b = 0; b < (int)DIEE_BANDS; ++b) { stats->band_seconds[b] = W.band_seconds[b]; stats->band_launches[b] = W.band_launches[b]; stats->band_flops[b] = W.band_flops[b]; stats->band_flops_demanded[b] = W.band_flops_demanded[b]; }
     }
 }
 void nn_reset_timing(Engine& e) {
@@ -711,7 +722,7 @@ void nn_reset_timing(Engine& e) {
     e.net->tower_seconds = 0; e.net->tower_launches = 0; e.net->tower_flops = 0;
     e.net->cluster_seconds = 0; e.net->cluster_launches = 0; e.net->cluster_flops = 0;
     e.net->full_seconds = 0; e.net->full_launches = 0; e.net->full_flops = 0;
-    for (int b = 0; b < (int)DIEE_BANDS; ++b) { e.net->band_seconds[b] = 0; e.net->band_launches[b] = 0; e.net->band_flops[b] = 0; }
+    for (int b = 0; b < (int)DIEE_BANDS; ++b) { e.net->band_seconds[b] = 0; e.net->band_launches[b] = 0; e.net->band_flops[b] = 0; e.net->band_flops_demanded[b] = 0; }
 }
 
 #ifdef DIEE_DEV_BUILD

@@ -73,11 +73,12 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; int boards; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; int boards; int dem_seq = -1; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
                                     // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
     bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
     int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)
     DevBuf<uint32_t> rows_log;      // [kRowsLog] rows evaluated by the compacted forward number (forward_count mod kRowsLog)
+    DevBuf<uint32_t> dem_log;       // [kRowsLog] ... of which DEMANDED by the search (tail / free-running launches: the others are speculative)
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     int sample_every = 17;
@@ -86,6 +87,7 @@ struct NetWeights {
     uint64_t conv_launches = 0, tower_launches = 0, cluster_launches = 0;
     double full_seconds = 0, full_flops = 0;      // the subset of the fused-tower samples that were ONE k_tower16<4,8,3> launch
     uint64_t full_launches = 0;
+    double band_flops_demanded[DIEE_BANDS] = {};                         // band_flops without the rows evaluated on speculation
     double band_seconds[DIEE_BANDS] = {}, band_flops[DIEE_BANDS] = {};   // every sample again, by the boards its launch(es) were dispatched for
     uint64_t band_launches[DIEE_BANDS] = {};
     hipEvent_t get_event() {
@@ -113,9 +115,11 @@ const char* nn_kernel_name(int family, int geometry);
 struct DispatchBand { int boards_min, boards_max, family, geometry; };
 std::vector<DispatchBand> nn_dispatch_bands(Engine& e, int upto);
 bool nn_tail_available(Engine& e, int G_upper, int n);
-bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band);
+bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint32_t* n_rows_dev, float* hv_out, float* logits_out, int boards_band,
+                     const uint32_t* n_dem_dev = nullptr);
 bool nn_free_available(Engine& e, int n);
-void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band);
+void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_idx, const uint32_t* n_rows_dev, int rows_upper, float* hv_out, float* logits_out, int boards_band,
+                     const uint32_t* n_dem_dev = nullptr);
 bool nn_cluster_used(Engine& e);
 void nn_disable_cluster(Engine& e);
 void nn_reset_cluster(Engine& e);

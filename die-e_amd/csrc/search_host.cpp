@@ -37,7 +37,7 @@ struct SearchBufs {
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
     // the tail of a batch (search_types.h, Tail)
-    DevBuf<uint32_t> tl_crow, tl_rows_node, tl_words;          // tl_words = n_rows[launches] ++ state[4] ++ bar[2 * launches + 8]
+    DevBuf<uint32_t> tl_crow, tl_rows_node, tl_words;          // tl_words = n_rows[launches] ++ state[4] ++ bar[2 * launches + 8] ++ bar2[launches] ++ n_dem[launches]
     DevBuf<float> tl_cval, tl_logits, tl_hv;
     DevBuf<BgState> tl_rows_state;
     uint32_t* tl_host = nullptr;                               // pinned, [4]
@@ -286,12 +286,12 @@ Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
         B.tl_crow.ensure((size_t)kTailMaxSlots * nc); B.tl_cval.ensure((size_t)kTailMaxSlots * nc);
         B.tl_rows_state.ensure((size_t)L * R); B.tl_rows_node.ensure((size_t)L * R);
         B.tl_logits.ensure((size_t)L * R * 1352); B.tl_hv.ensure((size_t)L * R * 72);
-        B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8 + (size_t)L);
+        B.tl_words.ensure((size_t)L + 4 + 2 * (size_t)L + 8 + (size_t)L + (size_t)L);
         B.tl_launches = L; B.tl_node_cap = nc; B.tl_rows_cap = R;
     }
     if (!B.tl_host) { HIPCHK(hipHostMalloc((void**)&B.tl_host, sizeof(uint32_t) * 4)); memset(B.tl_host, 0, sizeof(uint32_t) * 4); }
     uint32_t* w = B.tl_words.p;
-    return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + B.tl_launches, w + B.tl_launches + 4,
+    return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + 4 * (size_t)B.tl_launches + 12, w + B.tl_launches, w + B.tl_launches + 4,
                 w + B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8, B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n),
                 e.opt.spec_child_rows, e.opt.spec_extra_rows};
 }
@@ -307,7 +307,7 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     hipStream_t st = e.stream;
     // crow of the slots in use (the trees are rebuilt every move-step), the row counts, state words and meeting words
     HIPCHK(hipMemsetAsync(L.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
-    HIPCHK(hipMemsetAsync(B.tl_words.p, 0, sizeof(uint32_t) * ((size_t)B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8 + (size_t)L.launches), st));
+    HIPCHK(hipMemsetAsync(B.tl_words.p, 0, sizeof(uint32_t) * (5 * (size_t)B.tl_launches + 12), st));
     B.tl_host[1] = 0; B.tl_host[2] = 0xFFFFFFFFu;
     launch_tail(st, T, S, G, n, P, cfg.c, L, 0);
     uint32_t q = 0, sent = 0;
@@ -317,7 +317,7 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
         const uint32_t end = std::min<uint32_t>(cfg.iterations, q + std::max<uint32_t>(chunk, 1u));
         for (; q < end; ++q, ++sent) {
             if (!nn_forward_tail(e, L.rows_state + (size_t)q * L.rows, (int)L.rows, L.n_rows + q, L.hv + (size_t)q * L.rows * 72,
-                                 L.logits + (size_t)q * L.rows * 1352, (int)n))
+                                 L.logits + (size_t)q * L.rows * 1352, (int)n, L.n_dem + q))
                 throw EngineError(DIEE_ERR_HIP, "tail search: the cluster tower could not be launched");
             launch_tail(st, T, S, G, n, P, cfg.c, L, q + 1);
         }
@@ -368,13 +368,13 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
         B.fr_rows_idx.ensure((size_t)W * R); B.fr_logits.ensure((size_t)W * R * 1352); B.fr_hv.ensure((size_t)W * R * 72);
         B.fr_ring = W; B.fr_rows = R;
     }
-    if (launches > B.fr_launches) { B.fr_words.ensure((size_t)launches + 4); B.fr_launches = launches; }
+    if (launches > B.fr_launches) { B.fr_words.ensure(2 * (size_t)launches + 4); B.fr_launches = launches; }
     if (!B.fr_host) { HIPCHK(hipHostMalloc((void**)&B.fr_host, sizeof(uint32_t) * 2)); memset(B.fr_host, 0, sizeof(uint32_t) * 2); }
     if (!B.cus) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, e.device)); B.cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     uint32_t* sl = B.fr_slots.p;
     const uint32_t sc = B.fr_slot_cap;
-    return Free{B.fr_crow.p, B.fr_cval.p, B.fr_rows_idx.p, B.fr_logits.p, B.fr_hv.p, B.fr_words.p, sl, sl + sc, B.fr_wish.p, sl + 2 * (size_t)sc, sl + 3 * (size_t)sc,
-                sl + 4 * (size_t)sc, B.fr_words.p + B.fr_launches, B.fr_host, launches, cfg.iterations, rows, ring,
+    return Free{B.fr_crow.p, B.fr_cval.p, B.fr_rows_idx.p, B.fr_logits.p, B.fr_hv.p, B.fr_words.p, B.fr_words.p + B.fr_launches, sl, sl + sc, B.fr_wish.p, sl + 2 * (size_t)sc, sl + 3 * (size_t)sc,
+                sl + 4 * (size_t)sc, B.fr_words.p + 2 * (size_t)B.fr_launches, B.fr_host, launches, cfg.iterations, rows, ring,
                 std::min<uint32_t>(free_lds_nodes_for(n, (uint32_t)B.cus), std::max<uint32_t>(e.opt.free_lds_nodes, 64u)), e.opt.free_rollout_steps, e.opt.free_cand_max};
 }
 
@@ -389,7 +389,7 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     // crow of the slots in use (the trees are rebuilt every move-step), the row counts and state words, the per-slot progress (first_sel is
     // written by round 0)
     HIPCHK(hipMemsetAsync(F.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
-    HIPCHK(hipMemsetAsync(B.fr_words.p, 0, sizeof(uint32_t) * ((size_t)B.fr_launches + 4), st));
+    HIPCHK(hipMemsetAsync(B.fr_words.p, 0, sizeof(uint32_t) * (2 * (size_t)B.fr_launches + 4), st));
     HIPCHK(hipMemsetAsync(B.fr_slots.p, 0, sizeof(uint32_t) * (size_t)5 * B.fr_slot_cap, st));
     B.fr_host[0] = 0; B.fr_host[1] = 0xFFFFFFFFu;
     launch_free(st, T, S, G, n, P, cfg.c, F, 0);
@@ -400,7 +400,7 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
         const uint32_t end = std::min<uint32_t>(cfg.iterations + 1, q + std::max<uint32_t>(chunk, 1u));
         for (; q < end; ++q, ++sent) {
             const size_t rb = (size_t)(q % F.ring) * F.rows;
-            nn_forward_free(e, T.state, F.rows_idx + rb, F.n_rows + q, (int)F.rows, F.hv + rb * 72, F.logits + rb * 1352, (int)n);
+            nn_forward_free(e, T.state, F.rows_idx + rb, F.n_rows + q, (int)F.rows, F.hv + rb * 72, F.logits + rb * 1352, (int)n, F.n_dem + q);
             launch_free(st, T, S, G, n, P, cfg.c, F, q + 1);
         }
         HIPCHK(hipGetLastError());

@@ -141,6 +141,7 @@ struct Tail {
     float* logits;          // [launches][rows][1352] the ring
     float* hv;              // [launches][rows][72]
     uint32_t* n_rows;       // [launches] rows of launch q (0: nothing to evaluate, the launch returns at once)
+    uint32_t* n_dem;        // [launches] ... of which demanded (the games whose selected leaf had no evaluation): the bench's accounting
     uint32_t* state;        // [0] next iteration, [1] done, [2] launches that carried rows, [3] rows evaluated on speculation
     uint32_t* bar;          // [2 * launches + 8] one word per meeting of the games' workgroups (zeroed per move-step)
     uint32_t* bar2;         // [launches] the meeting inside the plan of launch q (extra_rows: shares taken before the free rows left over are)
@@ -173,6 +174,7 @@ struct Free {
     float* logits;          // [ring][rows][1352]
     float* hv;              // [ring][rows][72]
     uint32_t* n_rows;       // [launches] rows of launch q
+    uint32_t* n_dem;        // [launches] ... of which demanded (a game's selected leaf waiting for its evaluation): the bench's accounting
     uint32_t* grant_off;    // [slots] first row of the slot in the launch planned last ...
     uint32_t* grant_cnt;    // [slots] ... and how many it got
     uint32_t* wish;         // [slots][kFreeWish] nodes, most wanted first

@@ -132,9 +132,12 @@ typedef struct {
     /* the tail of a batch (<= spec_max_games = 96 and 129 ... spec_fused_games = 256 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
      * they needed (one per iteration without it), and the rows those launches evaluated on speculation (all batches of the call,
      * reported with batch 0) */
-    uint64_t tail_iterations;
+    uint64_t tail_iterations;  /* (round 6: the iterations, launches and speculative rows of the free-running search at 257 ... 768 live games count here too) */
     uint64_t tail_launches;
     uint64_t tail_spec_rows;
+    /* band_flops without the rows evaluated on speculation: the FLOPs of the rows the search asked for (the demanded leaves of a tail /
+     * free-running launch; every row of a plain or compacted evaluation) */
+    double   band_flops_demanded[9];
 } diee_stats;
 
 /* Vec<MemoryFragment>, src/alphazero/alphazero.rs:68-73: host arrays owned by the engine (page-locked: every move-step's

@@ -28,7 +28,7 @@ int main(void) {
     F(diee_stats, full_seconds); F(diee_stats, full_launches); F(diee_stats, full_flops);
     F(diee_stats, deliver_seconds); F(diee_stats, deliver_bytes);
     F(diee_stats, band_seconds); F(diee_stats, band_launches); F(diee_stats, band_flops);
-    F(diee_stats, tail_iterations); F(diee_stats, tail_launches); F(diee_stats, tail_spec_rows);
+    F(diee_stats, tail_iterations); F(diee_stats, tail_launches); F(diee_stats, tail_spec_rows); F(diee_stats, band_flops_demanded);
     F(diee_fragments, n); F(diee_fragments, outcome); F(diee_fragments, ps); F(diee_fragments, state); F(diee_fragments, game);
     F(diee_batch, n_games); F(diee_batch, first_game_id); F(diee_batch, seed);
     printf("  \"sizeof.diee_stats\": %zu, \"sizeof.diee_fragments\": %zu, \"sizeof.diee_bg_state\": %zu,\n", sizeof(diee_stats),

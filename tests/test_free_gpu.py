@@ -39,6 +39,9 @@ def cfgs(oracle, iters, **kw):
 def roots_of(oracle, n, pick):
     walk = oracle.random_walk_states(321, 80)
     late = walk[walk["off"].max(axis=1) >= 12]
+    if pick == "late" and len(late) < n + 2:             # (many bear-off positions: more games)
+        walk = oracle.random_walk_states(321, 400)
+        late = walk[walk["off"].max(axis=1) >= 12]
     if pick == "late":                                   # bear-off: terminal leaves, idle iterations, stale slots (Q14), drained leaves (Q15)
         return late[2:2 + n]
     if pick == "mixed":                                  # a third bear-off, the rest from the opening to the middle game
