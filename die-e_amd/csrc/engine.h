@@ -71,6 +71,7 @@ struct Options {
     uint32_t free_min_games = 257, free_max_games = 768;     // (<= 1024: k_free_pack runs one thread per game)
     uint32_t free_rows1024_from = 449;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512
     uint32_t free_rollout_steps = 12, free_cand_max = 6;     // virtual descents / candidates per game and round at most
+    uint32_t free_iter_cap = 4;             // iterations a game runs in one of its launches at most
     uint32_t free_ring = 128;               // launches whose rows stay in its ring (a row that aged out is evaluated again: same bits)
     uint32_t free_lds_nodes = 3072;         // cap of the tree nodes k_free stages in LDS per game (tests lower it to reach the in-place path)
     uint32_t spec_ring_mb = 8192;           // HBM the tail's ring of evaluated rows may take (MiB): (iterations + 1) launches x rows x 5.7 KB; a search whose ring

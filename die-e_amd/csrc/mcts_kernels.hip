@@ -1212,10 +1212,11 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     BgState lst = load_state(&S.eval_states[slot]);             // the selected leaf's state
     bool have = false, stalled = false;
     uint32_t minprog = 0;                                       // a lower bound of the batch's progress (every game has published iteration 0's selection)
-    for (;;) {
+    for (uint32_t ran = 0;; ++ran) {
         const uint32_t cr = lterm ? 0u : crow_of(leaf);
         have = lterm || at_hand(cr);
         if (!have) break;
+        if (ran >= F.iter_cap) { stalled = true; break; }       // (enough for this launch: the other games' workgroups are done long since)
         // ---- the flag words of this iteration, where the game needs them ----
         uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
         const bool need_cnt = quirks && slot == seg_first && it < fsel;

@@ -190,6 +190,8 @@ struct Free {
     uint32_t lds_nodes;     // nodes of a game's tree staged in LDS (by the workgroups that share a CU)
     uint32_t rollout_steps; // virtual descents per game and round at most
     uint32_t cand_max;      // candidates a game lists at most (< kFreeWish)
+    uint32_t iter_cap;      // iterations a game runs in one launch at most: the launch lasts as long as its busiest game (a game whose leaves are
+                            // finished games needs no rows and would run its whole search in the first one)
 };
 
 struct SearchParams {

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 SEED = 0xD1EE0001
 KEYS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
 DEFAULTS = dict(free_eval=1, free_min_games=257, free_max_games=768, free_rows1024_from=449, free_rollout_steps=12, free_cand_max=6,
-                free_ring=128, free_lds_nodes=3072)
+                free_ring=128, free_lds_nodes=3072, free_iter_cap=4)
 
 
 @pytest.fixture(scope="module")
@@ -89,7 +89,7 @@ def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, qu
 
 
 @pytest.mark.parametrize("opts", [dict(free_lds_nodes=64), dict(free_ring=4), dict(free_rows1024_from=257), dict(free_rows1024_from=1024),
-                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128)])
+                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000)])
 def test_free_running_options_change_nothing(eng, oracle, opts):
     """the tree's nodes beyond the LDS capacity are read in place, a ring of 4 launches makes evaluations age out (they are demanded again:
     the same bits), 512- or 1024-row launches, many or few candidates: the same search"""
