@@ -1098,6 +1098,21 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
 constexpr int kFreeSpinFew = 48, kFreeFewGames = 64;
 constexpr uint32_t kFreeRowBits = 12;                        // crow = ((launch << kFreeRowBits) | row) + 1
 struct FreeArgs { Free F; uint32_t q; };
+// development builds (-DDIEE_TAIL_STAMPS): shader-clock sums per phase of k_free over all workgroups, read by tests/tools/free_phases.py
+#ifdef DIEE_TAIL_STAMPS
+__device__ unsigned long long g_free_stamps[16];    // 0 record + tree into LDS + take-in, 1 flag words, 2 iteration body, 3 selection, 4 record out + plan; 8 workgroups, 9 iterations, 10 sum of the
+                                                    // launches' busiest workgroup is not known here: 10 = the longest single workgroup, 11 = virtual descents
+#define FR_STAMP(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_free_stamps[i], tn_ - fr_prev_); fr_prev_ = __builtin_readcyclecounter(); } while (0)
+#define FR_COUNT(i, k) do { if (threadIdx.x == 0) atomicAdd(&g_free_stamps[i], (unsigned long long)(k)); } while (0)
+extern "C" int diee_dev_free_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_free_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_free_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define FR_STAMP(i) do {} while (0)
+#define FR_COUNT(i, k) do {} while (0)
+#endif
 __host__ __device__ constexpr size_t free_lds_bytes(uint32_t ln) {
     return (size_t)ln * 36u + sizeof(WaveScratch) + sizeof(float) * kMaxPlays + sizeof(uint16_t) * kMaxPlays + sizeof(uint32_t) * 64u;
 }
@@ -1131,6 +1146,11 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     if (F.state[0] != 0u) return;                               // every game was done when the previous round was packed
     uint32_t it = F.prog[slot];
     if (it >= F.iterations) { if (lane == 0) F.wish_n[slot] = it << 8; return; }
+#ifdef DIEE_TAIL_STAMPS
+    unsigned long long fr_prev_ = __builtin_readcyclecounter();
+    const unsigned long long fr_t0_ = fr_prev_;
+#endif
+    FR_COUNT(8, 1);
     const uint32_t ln = F.lds_nodes;
     float* lvis = (float*)free_smem; float* lval = lvis + ln; float* lpri = lval + ln; float* lcval = lpri + ln;
     float* vvis = lcval + ln; float* vval = vvis + ln;
@@ -1210,6 +1230,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         return (uint32_t)(-wave_allmax_i32(-m));
     };
     BgState lst = load_state(&S.eval_states[slot]);             // the selected leaf's state
+    FR_STAMP(0);
     bool have = false, stalled = false;
     uint32_t minprog = 0;                                       // a lower bound of the batch's progress (every game has published iteration 0's selection)
     for (uint32_t ran = 0;; ++ran) {
@@ -1238,6 +1259,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             }
             if (!fin) { stalled = true; break; }
         }
+        FR_STAMP(1);
         const NetRowLoaded pre = [&] {
             NetRowLoaded p;
             const size_t ring = lterm ? 0u : (size_t)(((cr - 1u) >> kFreeRowBits) % F.ring) * F.rows + ((cr - 1u) & ((1u << kFreeRowBits) - 1u));
@@ -1326,6 +1348,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             }
             __syncthreads();
         }
+        FR_STAMP(2);
         // ================= selection for iteration it + 1 (select_slot on the LDS copy), published for the other games =================
         if (it + 1 < F.iterations) {
             uint32_t* nflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it + 1);
@@ -1394,6 +1417,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         __syncthreads();
         // the flags before the progress: whoever reads `it` here finds this game's words of iteration `it` in place
         if (lane == 0) { __threadfence(); atomicExch(&F.prog[slot], it); }
+        FR_STAMP(3); FR_COUNT(9, 1);
         if (it >= F.iterations) break;
     }
     // ---- the record for the next launch (and for whoever reads the slot after the search) ----
@@ -1453,6 +1477,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 if (fresh) { if (lane == 0) { cand[ncand] = node; wl[nw + ncand] = node; } ++ncand; fruitless = 0; } else ++fruitless;
                 if ((uint32_t)lane <= depth && mine < nu) { vvis[mine] += 1.0f; vval[mine] += x; }
                 __syncthreads();
+                FR_COUNT(11, 1);
             }
         }
         nw += ncand;
@@ -1461,6 +1486,10 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         F.wish_n[slot] = nw | (it << 8) | (dem ? 0x80000000u : 0u);
         store_counters(S, slot, cn);
     }
+    FR_STAMP(4);
+#ifdef DIEE_TAIL_STAMPS
+    if (threadIdx.x == 0) atomicMax(&g_free_stamps[10], __builtin_readcyclecounter() - fr_t0_);
+#endif
 }
 
 // The rows of launch q: every demanded leaf, then the other wishes rank by rank (every game's first candidate, then every game's second ...)
