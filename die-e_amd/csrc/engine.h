@@ -62,14 +62,15 @@ struct Options {
                                             // hand, speculative rows in the launches in between (search_types.h, Tail); 0: one launch per iteration
     uint32_t spec_rollout_steps = 24;       // virtual descents per game and launch that look for those rows (0: demanded rows only)
     uint32_t spec_fused_from = 129;         // live games from which a tail launch is one of the fused family (where tower_table sends the plain evaluations of so many boards)
-    uint32_t spec_fused_games = 256;        // 129 ... this many live games search in tail mode too, on 512-row launches of the fused family (<= 256; 0: off)
+    uint32_t spec_fused_games = 256;        // 129 ... this many live games search in tail mode too, on 512-row launches of the fused family (<= 256; 0: off) -- where the
+                                            // free-running search does not take them (free_eval = 0, or free_min_games above): round 6 measured it 8 ... 15 % faster there
     uint32_t spec_child_rows = 16;          // children of a demanded leaf that are evaluated in the same tail launch as the leaf at most (created ahead; 0: off)
     uint32_t spec_extra_rows = 2;           // candidates a game may find beyond its share of a full tail launch: they take the rows other games left free
     uint32_t spec_max_games = 96;           // live games up to which a move-step's search runs in tail mode (<= 128 = kTailMaxSlots; beyond 64 a launch has fewer spare rows than games)
     uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
     int free_eval = 1;                      // the free-running search (search_types.h, Free) at free_min_games ... free_max_games live games; 0: one launch per iteration there
-    uint32_t free_min_games = 257, free_max_games = 768;     // (<= 1024: k_free_pack runs one thread per game)
-    uint32_t free_rows1024_from = 449;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512
+    uint32_t free_min_games = 129, free_max_games = 768;     // (from 129: the plain evaluations of so many boards are of the fused family; <= 1024: k_free_pack runs one thread per game)
+    uint32_t free_rows1024_from = 200;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512 (profiles/r06e_*)
     uint32_t free_rollout_steps = 12, free_cand_max = 6;     // virtual descents / candidates per game and round at most
     uint32_t free_iter_cap = 4;             // iterations a game runs in one of its launches at most
     uint32_t free_ring = 128;               // launches whose rows stay in its ring (a row that aged out is evaluated again: same bits)

@@ -460,16 +460,16 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     const SearchParams P{cfg.dir_eps, quirks};
     // one MCTS kernel per network evaluation: expand + backpropagate iteration it, then select for it+1
     launch_expand(st, T, S, G, n, kRootIteration, P, cfg.iterations ? 0u : kNoNextIteration, cfg.c, grown, xv);
-    if (tail_possible(e, n, cfg)) {
+    if (free_possible(e, n, cfg)) {                                  // 129 ... 768 live games: every game on its own iteration counter
         S.slot_row = nullptr;
-        tail_run(e, n, T, S, G, cfg, P);
+        free_run(e, n, T, S, G, cfg, P);
         launch_reduce_counters(st, S, G);
         HIPCHK(hipGetLastError());
         return;
     }
-    if (free_possible(e, n, cfg)) {
+    if (tail_possible(e, n, cfg)) {                                  // <= 96 live games: the games in lockstep inside one launch
         S.slot_row = nullptr;
-        free_run(e, n, T, S, G, cfg, P);
+        tail_run(e, n, T, S, G, cfg, P);
         launch_reduce_counters(st, S, G);
         HIPCHK(hipGetLastError());
         return;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 SEED = 0xD1EE0001
 KEYS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
-DEFAULTS = dict(free_eval=1, free_min_games=257, free_max_games=768, free_rows1024_from=449, free_rollout_steps=12, free_cand_max=6,
+DEFAULTS = dict(free_eval=1, free_min_games=129, free_max_games=768, free_rows1024_from=200, free_rollout_steps=12, free_cand_max=6,
                 free_ring=128, free_lds_nodes=3072, free_iter_cap=4)
 
 
@@ -60,7 +60,7 @@ def check(res, roots, probs, ostats, name):
 
 
 @pytest.mark.parametrize("quirks", [1, 0])
-@pytest.mark.parametrize("n,iters,pick", [(257, 40, "mixed"), (300, 100, "mid"), (448, 30, "mixed"), (449, 30, "mixed"), (513, 40, "mixed"),
+@pytest.mark.parametrize("n,iters,pick", [(129, 40, "mixed"), (199, 40, "mid"), (200, 40, "mixed"), (257, 40, "mixed"), (300, 100, "mid"), (448, 30, "mixed"), (513, 40, "mixed"),
                                           (600, 100, "mid"), (700, 24, "late"), (768, 40, "mixed")])
 def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     states = roots_of(oracle, n, pick)
@@ -82,13 +82,13 @@ def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, qu
     assert d["tail_spec_rows"] == 0 and d["tail_launches"] <= iters + 1
     assert f["tail_launches"] <= d["tail_launches"]
     if pick != "late":                                   # the speculation pays: about 0.91 * n / rows launches per iteration (+ what the predictions miss)
-        rows = 1024 if n >= 449 else 512
+        rows = 1024 if n >= 200 else 512
         assert f["tail_spec_rows"] > 0 and f["tail_launches"] <= min(1.0, 1.45 * n / rows + 0.08) * iters, (f["tail_launches"], iters)
     print(f"[free] {n} games x {iters} iterations ({pick}, quirks {quirks}): {f['tail_launches']} launches with rows, {f['tail_spec_rows']} speculative rows "
           f"(demanded only: {d['tail_launches']})")
 
 
-@pytest.mark.parametrize("opts", [dict(free_lds_nodes=64), dict(free_ring=4), dict(free_rows1024_from=257), dict(free_rows1024_from=1024),
+@pytest.mark.parametrize("opts", [dict(free_lds_nodes=64), dict(free_ring=4), dict(free_rows1024_from=129), dict(free_rows1024_from=1024),
                                   dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000)])
 def test_free_running_options_change_nothing(eng, oracle, opts):
     """the tree's nodes beyond the LDS capacity are read in place, a ring of 4 launches makes evaluations age out (they are demanded again:

@@ -262,9 +262,13 @@ def test_the_searchs_compacted_and_tail_launches_are_of_the_tolerance_tested_fam
     e, _, _ = setup
     walk = oracle.random_walk_states(5, 30)
     cfg = diee_amd.MctsConfig(iterations=3, c=2.0, round_limit=400, dir_alpha=0.3, dir_eps=0.25)
+    e.alpha_mcts_parallel(walk[:900], cfg, 1, 0, np.arange(900, dtype=np.uint32), np.zeros(900, dtype=np.uint32), ref_quirks=True)
+    (k, boards), = e.last_dispatch()
+    assert k.startswith("k_tower16 (compacted") and boards == 900
+    # 129 ... 768 live games: the free-running search's launches are the same compacted-batch launches over up to 1024 rows gathered from the tree arena
     e.alpha_mcts_parallel(walk[:700], cfg, 1, 0, np.arange(700, dtype=np.uint32), np.zeros(700, dtype=np.uint32), ref_quirks=True)
     (k, boards), = e.last_dispatch()
-    assert k.startswith("k_tower16 (compacted") and boards == 700
+    assert k.startswith("k_tower16 (compacted") and boards == 1024
     for n, launch in ((3, ("k_tower_cl<1, 8>", 32)), (6, ("k_tower_cl<2, 8>", 64)), (40, ("k_tower_cl<4, 8>", 128))):
         e.alpha_mcts_parallel(walk[:n], cfg, 1, 0, np.arange(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32), ref_quirks=True)
         assert e.last_dispatch() == [launch], n

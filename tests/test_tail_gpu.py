@@ -58,11 +58,13 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
     res = {}
     for name, opts in (("tail", dict(spec_eval=1, spec_rollout_steps=24)), ("demanded rows only", dict(spec_eval=1, spec_rollout_steps=0, spec_child_rows=0)),
                        ("launch per iteration", dict(spec_eval=0, spec_rollout_steps=24))):
-        eng.set_options(spec_max_games=128, **opts)              # (the default reach is 96 games: the 128-game case asks for the kernel's whole range)
+        # (the default reach is 96 games: the 128-game case asks for the kernel's whole range; from 129 games on the free-running search
+        # takes a move-step by default since round 6 -- tests/test_free_gpu.py --: off here, so that k_tail's fused-family launches stay held to the oracle)
+        eng.set_options(spec_max_games=128, free_eval=0, **opts)
         try:
             res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 9, gids, rds, ref_quirks=bool(quirks))
         finally:
-            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96, spec_child_rows=CHILD_ROWS)
+            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96, spec_child_rows=CHILD_ROWS, free_eval=1)
     os_ = ostats.as_dict()
     for name, r in res.items():
         assert r["probs"].tobytes() == probs.tobytes(), (name, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
