@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
 // The rows of launch q: every demanded leaf, then the other wishes rank by rank (every game's first candidate, then every game's second ...)
 // until the launch is full; a game's rows are contiguous (k_free takes them in by grant_off / grant_cnt).  One workgroup, one thread per game,
 // the games in an order that turns with the launch (the rank that does not fit whole goes to the games that come first).
-__global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t node_cap, uint32_t q) {
+__global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t node_cap, uint32_t q, const BgState* __restrict__ arena) {
     __shared__ uint32_t hist[kFreeWish + 1];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_full, s_rem, s_dem, s_undone;
@@ -1550,6 +1550,10 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
         uint32_t* out = F.rows_idx + (size_t)(q % F.ring) * F.rows + off;
         const uint32_t* wl = F.wish + (size_t)g * kFreeWish;
         for (uint32_t j = 0; j < fit; ++j) out[j] = g * node_cap + wl[j];
+        if (F.rows_state) {                                     // (launches of the cluster family read their rows densely)
+            BgState* so = F.rows_state + (size_t)(q % F.ring) * F.rows + off;
+            for (uint32_t j = 0; j < fit; ++j) store_state(&so[j], load_state(&arena[(size_t)g * node_cap + wl[j]]));
+        }
     }
     if (tid == 0) {
         if (total > F.rows) total = F.rows;
@@ -1947,7 +1951,7 @@ void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
         attr_set[dev & 15] = true;
     }
     hipLaunchKernelGGL(k_free, dim3(n), dim3(64), free_lds_bytes(F.lds_nodes), st, T, S, G, n, P, c, FreeArgs{F, q});
-    hipLaunchKernelGGL(k_free_pack, dim3(1), dim3(1024), 0, st, F, n, T.node_cap, q);
+    hipLaunchKernelGGL(k_free_pack, dim3(1), dim3(1024), 0, st, F, n, T.node_cap, q, T.state);
 }
 void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);

@@ -47,6 +47,7 @@ struct SearchBufs {
     // the free-running search (search_types.h, Free)
     DevBuf<uint32_t> fr_crow, fr_rows_idx, fr_words, fr_slots, fr_wish;      // fr_words = n_rows[launches] ++ state[4]; fr_slots = grant_off ++ grant_cnt ++ wish_n ++ prog ++ first_sel, [slots] each
     DevBuf<float> fr_cval, fr_logits, fr_hv;
+    DevBuf<BgState> fr_rows_state;                              // dense states of the launches of at most 128 rows (cluster family)
     uint32_t* fr_host = nullptr;                                // pinned, [2]
     uint32_t fr_launches = 0, fr_ring = 0, fr_rows = 0, fr_slot_cap = 0, fr_node_cap = 0;
     uint32_t fr_prev_need = 0;
@@ -345,16 +346,23 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
 // ---- the free-running search (search_types.h, Free) -----------------------------------------------------------------------------
 // rows of a launch: up to 512 live games the 4-board pair tower's 512 rows (~300 us), beyond one pass of the chip (1024 rows, ~577 us); a
 // game needs 0.91 rows per iteration and the virtual descents see about one iteration ahead, so more than ~2 rows per game and launch are not used
-uint32_t free_rows_for(const Engine& e, uint32_t n) { return n >= e.opt.free_rows1024_from ? 1024u : 512u; }
+// (at most 128 live games: the plain evaluations are of the split-K cluster family, and so are the launches: 32 / 64 / 128 dense rows like the tail's)
+uint32_t free_rows_for(const Engine& e, uint32_t n) {
+    if (n <= kTailRowsMax) { const uint32_t r = tail_rows_for(e, n); return r > kTailRowsMax ? kTailRowsMax : r; }
+    return n >= e.opt.free_rows1024_from ? 1024u : 512u;
+}
 bool free_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
     if (e.opt.free_eval == 0 || cfg.iterations < 1 || cfg.iterations >= (1u << 22)) return false;
     if (n < e.opt.free_min_games || n > std::min<uint32_t>(e.opt.free_max_games, kFreeMaxSlots)) return false;
-    if (free_rows_for(e, n) < n) return false;                    // every live game's demanded leaf must fit the launch
-    return nn_free_available(e, (int)n);
+    const uint32_t rows = free_rows_for(e, n);
+    if (rows < n) return false;                                   // every live game's demanded leaf must fit the launch
+    if (e.net && e.net->invariant) return nn_free_available(e, (int)n);      // (DIEE_FLAG_INVARIANT_NN: every size on the fused family)
+    return n <= kTailRowsMax ? nn_tail_available(e, (int)rows, (int)n) : nn_free_available(e, (int)n);
 }
 
 Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
-    const uint32_t launches = cfg.iterations + 2, rows = free_rows_for(e, n);
+    const bool fused = n > kTailRowsMax || (e.net && e.net->invariant);
+    const uint32_t launches = cfg.iterations + 2, rows = fused && n <= kTailRowsMax ? 512u : free_rows_for(e, n);
     // the ring holds the rows of the last `ring` launches: a whole search at iterations = 100, option free_ring launches beyond
     const uint32_t ring = std::min<uint32_t>(launches, std::max<uint32_t>(e.opt.free_ring, 4u));
     if (n > B.fr_slot_cap || B.node_cap > B.fr_node_cap) {
@@ -366,6 +374,7 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     if (ring > B.fr_ring || rows > B.fr_rows) {
         const uint32_t W = std::max(ring, B.fr_ring), R = std::max(rows, B.fr_rows);
         B.fr_rows_idx.ensure((size_t)W * R); B.fr_logits.ensure((size_t)W * R * 1352); B.fr_hv.ensure((size_t)W * R * 72);
+        B.fr_rows_state.ensure((size_t)W * std::min<uint32_t>(R, kTailRowsMax));
         B.fr_ring = W; B.fr_rows = R;
     }
     if (launches > B.fr_launches) { B.fr_words.ensure(2 * (size_t)launches + 4); B.fr_launches = launches; }
@@ -373,7 +382,7 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     if (!B.cus) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, e.device)); B.cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     uint32_t* sl = B.fr_slots.p;
     const uint32_t sc = B.fr_slot_cap;
-    return Free{B.fr_crow.p, B.fr_cval.p, B.fr_rows_idx.p, B.fr_logits.p, B.fr_hv.p, B.fr_words.p, B.fr_words.p + B.fr_launches, sl, sl + sc, B.fr_wish.p, sl + 2 * (size_t)sc, sl + 3 * (size_t)sc,
+    return Free{B.fr_crow.p, B.fr_cval.p, B.fr_rows_idx.p, fused ? nullptr : B.fr_rows_state.p, B.fr_logits.p, B.fr_hv.p, B.fr_words.p, B.fr_words.p + B.fr_launches, sl, sl + sc, B.fr_wish.p, sl + 2 * (size_t)sc, sl + 3 * (size_t)sc,
                 sl + 4 * (size_t)sc, B.fr_words.p + 2 * (size_t)B.fr_launches, B.fr_host, launches, cfg.iterations, rows, ring,
                 std::min<uint32_t>(free_lds_nodes_for(n, (uint32_t)B.cus), std::max<uint32_t>(e.opt.free_lds_nodes, 64u)), e.opt.free_rollout_steps,
                 // candidates per game and round: about twice the spare rows a game can hope for (what is not granted is found again next round), at most the option's
@@ -402,7 +411,11 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
         const uint32_t end = std::min<uint32_t>(cfg.iterations + 1, q + std::max<uint32_t>(chunk, 1u));
         for (; q < end; ++q, ++sent) {
             const size_t rb = (size_t)(q % F.ring) * F.rows;
-            nn_forward_free(e, T.state, F.rows_idx + rb, F.n_rows + q, (int)F.rows, F.hv + rb * 72, F.logits + rb * 1352, (int)n, F.n_dem + q);
+            if (F.rows_state) {
+                if (!nn_forward_tail(e, F.rows_state + rb, (int)F.rows, F.n_rows + q, F.hv + rb * 72, F.logits + rb * 1352, (int)n, F.n_dem + q))
+                    throw EngineError(DIEE_ERR_HIP, "free-running search: the cluster tower could not be launched");
+            } else
+                nn_forward_free(e, T.state, F.rows_idx + rb, F.n_rows + q, (int)F.rows, F.hv + rb * 72, F.logits + rb * 1352, (int)n, F.n_dem + q);
             launch_free(st, T, S, G, n, P, cfg.c, F, q + 1);
         }
         HIPCHK(hipGetLastError());

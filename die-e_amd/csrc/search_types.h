@@ -171,6 +171,7 @@ struct Free {
     uint32_t* crow;         // [slots][node_cap] 1 + launch * rows + row of a node's evaluation (0: none); valid while launch + ring > the current launch
     float* cval;            // [slots][node_cap] its value (virtual descents only)
     uint32_t* rows_idx;     // [ring][rows] arena index (slot * node_cap + node) of every row of a launch: the tower gathers its states through it
+    BgState* rows_state;    // [ring][rows] the rows' states, dense: what the cluster tower of a launch of at most 128 rows reads (null above: gathered by index)
     float* logits;          // [ring][rows][1352]
     float* hv;              // [ring][rows][72]
     uint32_t* n_rows;       // [launches] rows of launch q

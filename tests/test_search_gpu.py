@@ -79,12 +79,20 @@ def test_mcts_batch_bit_exact_across_tower_kernels(eng, oracle, n):
     ev, _ = gpu_eval(eng, oracle)
     gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 7
     roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, ev, None, SEED, 1, gids, rds, 1)
-    r = eng.alpha_mcts_parallel(states, gcfg, SEED, 1, gids, rds, ref_quirks=True)
-    assert r["probs"].tobytes() == probs.tobytes(), np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max()
-    assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all()
-    gs, os_ = r["stats"], ostats.as_dict()
-    for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
-        assert gs[key] == os_[key], (key, gs[key], os_[key])
+    # round 6: above 128 roots the default search is the free-running one (tests/test_free_gpu.py); the launch-per-iteration search behind it
+    # (free_eval = 0, spec_eval = 0: one plain / compacted evaluation per iteration on the kernel of that size) stays held to the oracle here
+    for opts in (dict(), dict(free_eval=0, spec_eval=0)):
+        eng.set_options(**opts)
+        try:
+            r = eng.alpha_mcts_parallel(states, gcfg, SEED, 1, gids, rds, ref_quirks=True)
+        finally:
+            eng.set_options(free_eval=1, spec_eval=1)
+        assert r["probs"].tobytes() == probs.tobytes(), (opts, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
+        assert (r["root_visits"] == np.array([x["visits"] for x in roots], dtype=np.float32)).all()
+        gs, os_ = r["stats"], ostats.as_dict()
+        for key in ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children"):
+            assert gs[key] == os_[key], (opts, key, gs[key], os_[key])
+        assert (gs["tail_iterations"] == 0) == bool(opts)
 
 
 @pytest.mark.parametrize("n,iters", [(4, 400), (2, 1600)])
@@ -236,6 +244,7 @@ def test_compacted_evaluation_changes_nothing_but_the_row_count(oracle, monkeypa
     res = []
     for compact in ("1", "0"):
         e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0)); e.set_option("compact", compact)
+        e.set_option("free_eval", 0)                      # (600 games: the launch-per-iteration search, where the compaction lives)
         res.append(e.alpha_mcts_parallel(states, gcfg, SEED, 4, gids, rds, ref_quirks=True))
         e.close()
     a, b = res
@@ -315,6 +324,7 @@ def test_one_wave_and_two_wave_tree_kernels_agree(oracle, monkeypatch, n, iters)
     _, gcfg = cfgs(oracle, iters)
     gids = np.arange(n, dtype=np.uint32) + 5; rds = np.arange(n, dtype=np.uint32) % 3
     e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+    e.set_option("free_eval", 0)                          # (300 roots: the launch-per-iteration search, where k_expand runs every iteration)
     res = []
     for two, two_c in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         e.set_options(expand2=two, expand2c=two_c)
