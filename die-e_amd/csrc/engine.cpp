@@ -41,7 +41,7 @@ const OptEntry kOptions[] = {
     {"path_cap", nullptr, &Options::path_cap, nullptr}, {"nodes_per_expansion", nullptr, &Options::nodes_per_expansion, nullptr},
     {"deliver_stage_rows", nullptr, &Options::deliver_stage_rows, nullptr}, {"deliver_rows_per_game", nullptr, &Options::deliver_rows_per_game, nullptr},
     {"trace_steps", &Options::trace_steps, nullptr, nullptr}, {"trace_dispatch", &Options::trace_dispatch, nullptr, nullptr},
-    {"test_starve_at", &Options::test_starve_at, nullptr, nullptr},
+    {"test_starve_at", &Options::test_starve_at, nullptr, nullptr}, {"test_tail_skip", &Options::test_tail_skip, nullptr, nullptr},
     {"pinned_pool_mb", nullptr, nullptr, nullptr},          // process-wide: the cap of the pool of page-locked output blocks (search_host.cpp)
 };
 const OptEntry* find_option(const std::string& key) {

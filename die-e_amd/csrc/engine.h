@@ -82,6 +82,7 @@ struct Options {
     uint32_t deliver_stage_rows = 16384, deliver_rows_per_game = 128;
     // development traces on stderr
     int trace_steps = 0, trace_dispatch = 0;
+    int test_tail_skip = 0;                 // tests: 1 + the meeting word of the next tail search at which one game's workgroup never arrives (k_tail's device-side time-out)
     int test_starve_at = 0;                 // tests: the k-th hand-over check of this ctx reports a starved hand-over (0: never)
 };
 

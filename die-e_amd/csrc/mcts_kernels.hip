@@ -622,12 +622,12 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_expand(Tree T, Slots S, Segs
 constexpr int kTailSpin = 1 << 20;
 // the games' workgroups meet: every one has published its selection of iteration `it` (flags, selection record) and says whether its
 // leaf has its evaluation; returns the number of workgroups that said no.  One word per meeting, never reused within a move-step.
-__device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, int lane, uint32_t* err, uint32_t& misses) {
+__device__ __forceinline__ bool tail_meet(uint32_t* word, uint32_t n, bool hit, int lane, uint32_t* err, uint32_t& misses, bool absent = false) {
     if (n == 1) { misses = hit ? 0u : 1u; return true; }
     __threadfence();                                        // this workgroup's stores before its arrival
     uint32_t v = 0;
     if (lane == 0) {
-        atomicAdd(word, hit ? 1u : 0x10001u);
+        if (!absent) atomicAdd(word, hit ? 1u : 0x10001u);  // (absent: the test of the time-out path -- this workgroup waits like the others but never arrives)
         int spins = 0;
         for (;;) {
             v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(64) void k_tail(Tree T, Slots S, Segs G, uint32_t n
         NetRowLoaded pre;                                       // requested now, used behind the meeting
         pre.vh = value_head_load(L.hv + (size_t)ring * 72, S.wv, lane);
         softmax_load(L.logits + (size_t)ring * 1352, lane, pre.lg);
-        if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses)) {
+        if (!tail_meet(L.bar + it + A.q, n, hit, lane, S.overflow, misses, L.test_skip != 0u && slot == n - 1u && it + A.q + 1u == L.test_skip)) {
             if (lane == 0) { atomicMax(&L.state[1], 2u); L.host[1] = 2u; __threadfence_system(); }
             return;
         }
@@ -1113,25 +1113,32 @@ extern "C" int diee_dev_free_stamps(unsigned long long* out, int reset) {
 #define FR_STAMP(i) do {} while (0)
 #define FR_COUNT(i, k) do {} while (0)
 #endif
+// a node in LDS: visits, value, prior, one header word (expanded / finished-game bits, children, first child), the ring row of its evaluation, and
+// the virtual descents' copy of visits / value -- 28 bytes (the action code of Tree::meta and the evaluation's value stay in HBM: read where needed)
+constexpr uint32_t kFreeLdsNodeBytes = 28;
+__host__ __device__ __forceinline__ constexpr uint32_t free_hdr(uint32_t meta, uint32_t first_child) {
+    return (meta & 0xE0000000u) | (((meta >> 16) & 0x1ffu) << 20) | (first_child & 0xFFFFFu);
+}
+__host__ __device__ __forceinline__ constexpr uint32_t hdr_nch(uint32_t h) { return (h >> 20) & 0x1ffu; }
+__host__ __device__ __forceinline__ constexpr uint32_t hdr_fc(uint32_t h) { return h & 0xFFFFFu; }
 __host__ __device__ constexpr size_t free_lds_bytes(uint32_t ln) {
-    return (size_t)ln * 36u + sizeof(WaveScratch) + sizeof(float) * kMaxPlays + sizeof(uint16_t) * kMaxPlays + sizeof(uint32_t) * 64u;
+    return (size_t)ln * kFreeLdsNodeBytes + sizeof(WaveScratch) + sizeof(float) * kMaxPlays + sizeof(uint16_t) * kMaxPlays + sizeof(uint32_t) * 64u;
 }
 // the tree through LDS with a run-time capacity: nodes below `ln` live there (and in HBM, written through), the others in HBM alone
 struct TreeF {
     const Tree& T; size_t base; uint32_t ln;
-    float *lvis, *lval, *lpri; uint32_t *lmeta, *lfc;
+    float *lvis, *lval, *lpri; uint32_t* lhdr;
     __device__ __forceinline__ float vis(uint32_t i) const { return i < ln ? lvis[i] : T.visits[base + i]; }
     __device__ __forceinline__ float val(uint32_t i) const { return i < ln ? lval[i] : T.value[base + i]; }
     __device__ __forceinline__ float pri(uint32_t i) const { return i < ln ? lpri[i] : T.prior[base + i]; }
-    __device__ __forceinline__ uint32_t meta(uint32_t i) const { return i < ln ? lmeta[i] : T.meta[base + i]; }
-    __device__ __forceinline__ uint32_t fc(uint32_t i) const { return i < ln ? lfc[i] : T.first_child[base + i]; }
+    __device__ __forceinline__ uint32_t hdr(uint32_t i) const { return i < ln ? lhdr[i] : free_hdr(T.meta[base + i], T.first_child[base + i]); }
     __device__ __forceinline__ void add(uint32_t i, float v) const {          // visits += 1, value += v (simple_mcts.rs:96-103, one node)
         const float nv = vis(i) + 1.0f, nw = val(i) + v;
         if (i < ln) { lvis[i] = nv; lval[i] = nw; }
         T.visits[base + i] = nv; T.value[base + i] = nw;
     }
     __device__ __forceinline__ void set_header(uint32_t i, uint32_t m, uint32_t f) const {
-        if (i < ln) { lmeta[i] = m; lfc[i] = f; }
+        if (i < ln) lhdr[i] = free_hdr(m, f);
         T.meta[base + i] = m; T.first_child[base + i] = f;
     }
 };
@@ -1152,9 +1159,9 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
 #endif
     FR_COUNT(8, 1);
     const uint32_t ln = F.lds_nodes;
-    float* lvis = (float*)free_smem; float* lval = lvis + ln; float* lpri = lval + ln; float* lcval = lpri + ln;
-    float* vvis = lcval + ln; float* vval = vvis + ln;
-    uint32_t* lmeta = (uint32_t*)(vval + ln); uint32_t* lfc = lmeta + ln; uint32_t* lcrow = lfc + ln;
+    float* lvis = (float*)free_smem; float* lval = lvis + ln; float* lpri = lval + ln;
+    float* vvis = lpri + ln; float* vval = vvis + ln;
+    uint32_t* lhdr = (uint32_t*)(vval + ln); uint32_t* lcrow = lhdr + ln;
     WaveScratch& ws = *reinterpret_cast<WaveScratch*>(lcrow + ln);
     float* raw = reinterpret_cast<float*>(&ws + 1);
     uint16_t* code = reinterpret_cast<uint16_t*>(raw + kMaxPlays);
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     const size_t base = (size_t)slot * T.node_cap;
     uint32_t* crow_g = F.crow + base;
     float* cval_g = F.cval + base;
-    const TreeF X{T, base, ln, lvis, lval, lpri, lmeta, lfc};
+    const TreeF X{T, base, ln, lvis, lval, lpri, lhdr};
     const bool quirks = P.quirks != 0;
     // ---- the record the game carries from launch to launch ----
     const uint32_t seg = G.n == 1 ? 0u : S.seg[slot];
@@ -1197,10 +1204,19 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     }
     // ---- the tree's statistics into LDS; the rows the previous launch evaluated for this game on top ----
     const uint32_t nl = used < ln ? used : ln;
-    for (uint32_t i = lane; i < nl; i += 64) {
-        lvis[i] = T.visits[base + i]; lval[i] = T.value[base + i]; lpri[i] = T.prior[base + i];
-        lmeta[i] = T.meta[base + i]; lfc[i] = T.first_child[base + i];
-        lcrow[i] = crow_g[i]; lcval[i] = cval_g[i];
+    for (uint32_t i0 = 0; i0 < nl; i0 += 256) {                 // four rounds of loads in flight before the first store (a wave alone on its SIMD waits out every round trip)
+        float a[4], b[4], p[4]; uint32_t m[4], f[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * u + (uint32_t)lane;
+            const size_t gi = base + (i < nl ? i : 0u);
+            a[u] = T.visits[gi]; b[u] = T.value[gi]; p[u] = T.prior[gi]; m[u] = T.meta[gi]; f[u] = T.first_child[gi]; r[u] = crow_g[i < nl ? i : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * u + (uint32_t)lane;
+            if (i < nl) { lvis[i] = a[u]; lval[i] = b[u]; lpri[i] = p[u]; lhdr[i] = free_hdr(m[u], f[u]); lcrow[i] = r[u]; }
+        }
     }
     __syncthreads();
     if (A.q > 0) {
@@ -1215,7 +1231,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             const float cv = tanhf(dot + S.wv[72]);
             const uint32_t id = ((pq << kFreeRowBits) | row) + 1u;
             cval_g[node] = cv; crow_g[node] = id;
-            if (node < ln) { lcval[node] = cv; lcrow[node] = id; }
+            if (node < ln) lcrow[node] = id;
         }
         cn[SC_NN_ROWS] += cnt;
         __syncthreads();
@@ -1247,7 +1263,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             bool fin = false;
             const int spins = n <= (uint32_t)kFreeFewGames ? kFreeSpinFew : 1;
             for (int spin = 0; spin < spins; ++spin) {
-                if (!need_cnt && free_load(&iflag[0]) != 0u) { ifl.x = 1u; fin = true; break; }
+                // (a 1 is final however old the cache line it is read from; a 0 may be stale: ask the memory side)
+                if (!need_cnt && (iflag[0] != 0u || free_load(&iflag[0]) != 0u)) { ifl.x = 1u; fin = true; break; }
                 if (minprog < it) minprog = batch_progress();
                 if (minprog >= it) {                            // everybody has published this iteration's selection: the words are final
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1325,7 +1342,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                         T.visits[ci] = 0.0f; T.value[ci] = 0.0f; T.prior[ci] = prj;
                         T.parent[ci] = leaf; T.first_child[ci] = 0; T.meta[ci] = cm;
                         crow_g[cl] = 0u;                                         // (crow is zeroed per move-step; kept explicit: a node is born without an evaluation)
-                        if (cl < ln) { lvis[cl] = 0.0f; lval[cl] = 0.0f; lpri[cl] = prj; lmeta[cl] = cm; lfc[cl] = 0; lcrow[cl] = 0; lcval[cl] = 0.0f; }
+                        if (cl < ln) { lvis[cl] = 0.0f; lval[cl] = 0.0f; lpri[cl] = prj; lhdr[cl] = free_hdr(cm, 0u); lcrow[cl] = 0; }
                     }
                     const uint32_t nmeta = kDrained | ((uint32_t)k << 16) | (m0 & kMetaKeep);
                     if (lane == 0) X.set_header(leaf, nmeta, first);
@@ -1353,10 +1370,10 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         if (it + 1 < F.iterations) {
             uint32_t* nflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it + 1);
             uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone;
-            uint32_t mt = X.meta(0), fcn = X.fc(0);
+            uint32_t mt = X.hdr(0), fcn = hdr_fc(mt);
             float nvis = X.vis(0);
             for (;;) {
-                const uint32_t k = meta_nch(mt);
+                const uint32_t k = hdr_nch(mt);
                 if (k == 0) break;
                 const float sq = sqrtf(nvis);
                 Best b{0.0f, -1};
@@ -1392,7 +1409,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 node = fcn + (uint32_t)chosen;
                 ++depth;
                 if ((uint32_t)lane == depth) mine = node;
-                mt = X.meta(node); fcn = X.fc(node); nvis = X.vis(node);
+                mt = X.hdr(node); fcn = hdr_fc(mt); nvis = X.vis(node);
             }
             const uint32_t npl = depth < S.path_cap ? depth + 1u : 0u;
             cn[SC_SELECTIONS] += 1; cn[SC_DEPTH_SUM] += depth;
@@ -1404,7 +1421,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 lterm = true;
                 if (lane == 0 && quirks && sel == kNone) atomicAdd(&nflag[1], 1u);
             } else {
-                lterm = false; leaf = node; leaf_meta = mt; plen = npl; pnode = mine;
+                lterm = false; leaf = node; plen = npl; pnode = mine;
+                leaf_meta = T.meta[base + node];                // (the header word in LDS carries no action code: the expansion of this leaf keeps it, kMetaKeep)
                 if (lane == 0) {
                     atomicOr(&nflag[0], 1u);
                     if (sel == kNone) F.first_sel[slot] = it + 1u;
@@ -1449,10 +1467,10 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             for (uint32_t step = 0; step < F.rollout_steps && ncand < want && fruitless < 8; ++step) {
                 uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
                 for (;;) {
-                    mt = X.meta(node);
-                    const uint32_t k = meta_nch(mt);
+                    mt = X.hdr(node);
+                    const uint32_t k = hdr_nch(mt);
                     if (k == 0) break;
-                    const uint32_t fcn = X.fc(node);
+                    const uint32_t fcn = hdr_fc(mt);
                     const float sq = sqrtf(node < nu ? vvis[node] : T.visits[base + node]);
                     Best b{0.0f, -1};
                     for (uint32_t j = lane; j < k; j += 64) {
@@ -1472,7 +1490,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 float x = 0.0f;
                 bool fresh = false;
                 if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
-                else if (at_hand(cr)) x = node < ln ? lcval[node] : cval_g[node];
+                else if (at_hand(cr)) x = cval_g[node];
                 else if (!(mt & kDrained) && node != demanded) fresh = __ballot((uint32_t)lane < ncand && cand[lane] == node) == 0ull;
                 if (fresh) { if (lane == 0) { cand[ncand] = node; wl[nw + ncand] = node; } ++ncand; fruitless = 0; } else ++fruitless;
                 if ((uint32_t)lane <= depth && mine < nu) { vvis[mine] += 1.0f; vval[mine] += x; }
@@ -1938,8 +1956,8 @@ uint32_t free_lds_nodes_for(uint32_t n, uint32_t cus) {
     const uint32_t per_cu = (n + cus - 1) / (cus ? cus : 1u);
     const size_t budget = (size_t)160 * 1024 / (per_cu ? per_cu : 1u);
     const size_t fixed = free_lds_bytes(0);
-    if (budget <= fixed + 64 * 36) return 64;
-    uint32_t ln = (uint32_t)((budget - fixed) / 36) / 64 * 64;
+    if (budget <= fixed + 64 * kFreeLdsNodeBytes) return 64;
+    uint32_t ln = (uint32_t)((budget - fixed) / kFreeLdsNodeBytes) / 64 * 64;
     return ln > kTailLdsNodes ? kTailLdsNodes : ln;
 }
 void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Free& F, uint32_t q) {

@@ -268,6 +268,10 @@ uint32_t tail_rows_for(const Engine& e, uint32_t n) {
 bool tail_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
     if (e.opt.spec_eval == 0 || n < 1 || cfg.iterations < 1) return false;
     const uint32_t rows = tail_rows_for(e, n);
+    // k_tail's workgroups (one per game, > 100 KB of LDS each: one per compute unit) meet inside the launch: all of them must be resident together.
+    // A device (or a partition of one) with fewer compute units than live games searches launch by launch instead of timing out at every meeting.
+    if (!e.search->cus) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e.device) == hipSuccess) e.search->cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    if (e.search->cus && n > (uint32_t)e.search->cus) return false;
     if (rows < n) return false;      // (options spec_rows64_from / spec_rows128_from can ask for fewer rows than games: every live game needs its demanded row)
     // the ring of evaluated rows grows with the iterations ((iterations + 1) launches x rows x (1352 + 72) floats; crow / cval: 256 x node_cap words):
     // beyond option spec_ring_mb the search runs one launch per iteration instead of failing an allocation in mid-batch
@@ -294,7 +298,7 @@ Tail tail_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     uint32_t* w = B.tl_words.p;
     return Tail{B.tl_crow.p, B.tl_cval.p, B.tl_rows_state.p, B.tl_rows_node.p, B.tl_logits.p, B.tl_hv.p, w, w + 4 * (size_t)B.tl_launches + 12, w + B.tl_launches, w + B.tl_launches + 4,
                 w + B.tl_launches + 4 + 2 * (size_t)B.tl_launches + 8, B.tl_host, launches, cfg.iterations, e.opt.spec_rollout_steps, tail_rows_for(e, n),
-                e.opt.spec_child_rows, e.opt.spec_extra_rows};
+                e.opt.spec_child_rows, e.opt.spec_extra_rows, (uint32_t)e.opt.test_tail_skip};
 }
 
 // The iterations of one move-step's search for n <= kTailMaxSlots (option spec_max_games) live games, behind the root expansion (k_expand has selected every
@@ -335,6 +339,7 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     // a meeting that timed out raised the starved bit (and left 2 in the state word): this search is void, cluster_starved() repeats it
     // launch by launch -- whatever the done word says (a workgroup that gave up left its game's record unsaved)
     const bool starved = (flag_word & 4u) != 0u || words[1] == 2u;
+    if (L.test_skip) e.opt.test_tail_skip = 0;                       // (tests: one forced time-out per request)
     if (!done && !starved) throw EngineError(DIEE_ERR_HIP, "tail search: the iterations did not complete");
     if (starved) { B.tl_prev_need = 0; return; }
     if (e.opt.trace_steps)
@@ -347,8 +352,11 @@ void tail_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
 // rows of a launch: up to 512 live games the 4-board pair tower's 512 rows (~300 us), beyond one pass of the chip (1024 rows, ~577 us); a
 // game needs 0.91 rows per iteration and the virtual descents see about one iteration ahead, so more than ~2 rows per game and launch are not used
 // (at most 128 live games: the plain evaluations are of the split-K cluster family, and so are the launches: 32 / 64 / 128 dense rows like the tail's)
-uint32_t free_rows_for(const Engine& e, uint32_t n) {
-    if (n <= kTailRowsMax) { const uint32_t r = tail_rows_for(e, n); return r > kTailRowsMax ? kTailRowsMax : r; }
+// the launches of a search are of the arithmetic family of the plain evaluations of its n live games (what the oracle's evaluator runs):
+// the fused 16x16x32 family where tower_table sends so many boards (from 129 by default; every size under DIEE_FLAG_INVARIANT_NN), else the split-K cluster family
+bool free_fused(Engine& e, uint32_t n) { return nn_free_available(e, (int)n); }
+uint32_t free_rows_for(Engine& e, uint32_t n) {
+    if (!free_fused(e, n)) { const uint32_t r = tail_rows_for(e, n); return r > kTailRowsMax ? kTailRowsMax : r; }
     return n >= e.opt.free_rows1024_from ? 1024u : 512u;
 }
 bool free_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
@@ -356,13 +364,13 @@ bool free_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
     if (n < e.opt.free_min_games || n > std::min<uint32_t>(e.opt.free_max_games, kFreeMaxSlots)) return false;
     const uint32_t rows = free_rows_for(e, n);
     if (rows < n) return false;                                   // every live game's demanded leaf must fit the launch
-    if (e.net && e.net->invariant) return nn_free_available(e, (int)n);      // (DIEE_FLAG_INVARIANT_NN: every size on the fused family)
-    return n <= kTailRowsMax ? nn_tail_available(e, (int)rows, (int)n) : nn_free_available(e, (int)n);
+    if ((uint64_t)(cfg.iterations + 1) * std::max<uint32_t>(e.opt.nodes_per_expansion, 1) + 64 > (1u << 20)) return false;      // (k_free's header word holds 20 bits of node index)
+    return free_fused(e, n) || (n <= kTailRowsMax && nn_tail_available(e, (int)rows, (int)n));
 }
 
 Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
-    const bool fused = n > kTailRowsMax || (e.net && e.net->invariant);
-    const uint32_t launches = cfg.iterations + 2, rows = fused && n <= kTailRowsMax ? 512u : free_rows_for(e, n);
+    const bool fused = free_fused(e, n);
+    const uint32_t launches = cfg.iterations + 2, rows = free_rows_for(e, n);
     // the ring holds the rows of the last `ring` launches: a whole search at iterations = 100, option free_ring launches beyond
     const uint32_t ring = std::min<uint32_t>(launches, std::max<uint32_t>(e.opt.free_ring, 4u));
     if (n > B.fr_slot_cap || B.node_cap > B.fr_node_cap) {

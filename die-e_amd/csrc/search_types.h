@@ -152,6 +152,8 @@ struct Tail {
     uint32_t rows;          // rows of a launch in this move-step (32 / 64 / 128; 512 at 129 ... 256 live games)
     uint32_t child_rows;    // children of a demanded leaf (created ahead: their dice are keyed by the iteration that will expand it) that ride in its launch at most (0: off)
     uint32_t extra_rows;    // candidates a game may find beyond its share of a full launch's rows: they take what other games left free (0: off)
+    uint32_t test_skip;     // tests: 1 + the meeting word at which the last game's workgroup does NOT arrive (0: never): every workgroup's bounded
+                            // spin runs out, the starved bit is raised, the host repeats the move-step's search launch by launch
 };
 
 // ---- free-running search (round 6): 257 ... 928 live games ---------------------------------------------------------------------------

@@ -193,7 +193,7 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *                                 with several ranks per host: what each may retain)
  *   deliver_stage_rows, deliver_rows_per_game, nodes_per_expansion, path_cap        buffer sizes (tests)
  *   cl_pack, cl_grow, expand2, expand2c, spec_rollout_steps (virtual descents per game and launch, default 24), spec_fused_from, fused_heads, cluster_heads, cluster_init, trace_steps,
- *   trace_dispatch, test_starve_at                                                  development / test switches
+ *   trace_dispatch, test_starve_at, test_tail_skip                                                  development / test switches
  * Unknown key or malformed value: DIEE_ERR_ARG.  Not for a tic-tac-toe ctx (DIEE_ERR_UNSUPPORTED). */
 diee_status diee_set_option(diee_ctx*, const char* key, const char* value);
 diee_status diee_get_option(diee_ctx*, const char* key, char* value /*[cap]*/, size_t cap);

@@ -70,12 +70,12 @@ def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, qu
     roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(eng, oracle), None, SEED, 4, gids, rds, quirks)
     os_ = ostats.as_dict()
     res = {}
-    for name, opts in (("free-running", dict(free_eval=1)), ("demanded rows only", dict(free_eval=1, free_cand_max=0)), ("launch per iteration", dict(free_eval=0))):
+    for name, opts in (("free-running", dict(free_eval=1)), ("demanded rows only", dict(free_eval=1, free_cand_max=0)), ("launch per iteration", dict(free_eval=0, spec_eval=0))):
         eng.set_options(**opts)
         try:
             res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 4, gids, rds, ref_quirks=bool(quirks))
         finally:
-            eng.set_options(**DEFAULTS)
+            eng.set_options(spec_eval=1, **DEFAULTS)
         check(res[name], roots, probs, os_, name)
     f, d, p = (res[k]["stats"] for k in ("free-running", "demanded rows only", "launch per iteration"))
     assert f["tail_iterations"] == d["tail_iterations"] == iters and p["tail_iterations"] == 0
