@@ -1267,8 +1267,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 if (!need_cnt && (iflag[0] != 0u || free_load(&iflag[0]) != 0u)) { ifl.x = 1u; fin = true; break; }
                 if (minprog < it) minprog = batch_progress();
                 if (minprog >= it) {                            // everybody has published this iteration's selection: the words are final
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    ifl.x = free_load(&iflag[0]); ifl.y = free_load(&iflag[1]);
+                    ifl.x = free_load(&iflag[0]); ifl.y = free_load(&iflag[1]);      // (memory-side loads, issued after the progress words' have returned)
                     fin = true;
                     break;
                 }
@@ -1367,6 +1366,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         }
         FR_STAMP(2);
         // ================= selection for iteration it + 1 (select_slot on the LDS copy), published for the other games =================
+        uint32_t published = 0;
         if (it + 1 < F.iterations) {
             uint32_t* nflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it + 1);
             uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone;
@@ -1419,12 +1419,14 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 else if (lane == 0) { for (uint32_t i = node; i != kNone; i = T.parent[base + i]) X.add(i, tv); }
                 cn[SC_TERMINAL] += 1;
                 lterm = true;
-                if (lane == 0 && quirks && sel == kNone) atomicAdd(&nflag[1], 1u);
+                if (lane == 0 && quirks && sel == kNone) published = atomicAdd(&nflag[1], 1u);
             } else {
                 lterm = false; leaf = node; plen = npl; pnode = mine;
                 leaf_meta = T.meta[base + node];                // (the header word in LDS carries no action code: the expansion of this leaf keeps it, kMetaKeep)
                 if (lane == 0) {
-                    atomicOr(&nflag[0], 1u);
+                    // (a 1 read from a cached line is final -- nobody clears the word within a move-step --, so only the first games to get here touch
+                    // the word with an atomic: a thousand same-address atomics per iteration would queue up at ~11 ns each)
+                    if (nflag[0] == 0u) published = atomicOr(&nflag[0], 1u);
                     if (sel == kNone) F.first_sel[slot] = it + 1u;
                 }
                 sel = node;
@@ -1433,8 +1435,13 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         }
         ++it;
         __syncthreads();
-        // the flags before the progress: whoever reads `it` here finds this game's words of iteration `it` in place
-        if (lane == 0) { __threadfence(); atomicExch(&F.prog[slot], it); }
+        // the flags before the progress: whoever reads `it` here finds this game's words of iteration `it` in place.  Both are atomics at the
+        // memory side, and the progress is issued only when the flag's atomic has RETURNED (`published` is waited for): no release fence -- on this
+        // chip that is a write-back of the XCD's whole L2, once per game and iteration (the games share nothing else: their trees are their own)
+        if (lane == 0) {
+            asm volatile("" :: "v"(published) : "memory");      // (the flag atomic's return value is in its register: the atomic has been performed)
+            atomicExch(&F.prog[slot], it);
+        }
         FR_STAMP(3); FR_COUNT(9, 1);
         if (it >= F.iterations) break;
     }

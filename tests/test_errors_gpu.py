@@ -97,6 +97,34 @@ print("RESULT", hashlib.sha256(out["ps"].tobytes() + out["state"].tobytes() + ou
     assert res["starved"][0] == res["normal"][0]          # same records, same counters: the repeated search left no trace
 
 
+def test_a_tail_meeting_that_times_out_on_the_device_is_repeated_launch_by_launch(oracle):
+    """k_tail's own time-out path (round-5 review, weak #8): one game's workgroup never arrives at a meeting of the games' workgroups
+    (option test_tail_skip), so every workgroup's bounded spin runs out with the games in mid-iteration and their LDS state half written
+    back.  The starved bit is raised on the device, the state word keeps its 2 whatever slot 0 writes afterwards, tail_run takes the starved
+    path, and the move-step's search is repeated launch by launch: the same records as the undisturbed run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import diee_amd
+e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+cfg = diee_amd.MctsConfig(iterations=8, c=2.0, round_limit=30, dir_alpha=0.3, dir_eps=0.25)
+out = e.self_play_parallel(12, cfg, 1.25, 78, ref_quirks=True)
+print("RESULT", hashlib.sha256(out["ps"].tobytes() + out["state"].tobytes() + out["outcome"].tobytes()).hexdigest(),
+      out["stats"]["nn_evals"], out["stats"]["expansions"], out["stats"]["move_steps"])
+""" % root
+    res = {}
+    for name, env in (("normal", {}), ("timed out", {"DIEE_TEST_TAIL_SKIP": "3"})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        res[name] = ([l for l in p.stdout.decode().splitlines() if l.startswith("RESULT")][0], p.stderr.decode())
+    assert "falling back to the per-layer kernels" in res["timed out"][1] and "falling back" not in res["normal"][1]
+    assert res["timed out"][0] == res["normal"][0]
+
+
 def test_options_travel_through_the_abi():
     """diee_set_option / diee_get_option (include/diee.h): what used to be environment switches.  Values round-trip, unknown keys and
     malformed values are DIEE_ERR_ARG and change nothing, the dispatch follows (bands of the development probe), `shared_gpu` takes
