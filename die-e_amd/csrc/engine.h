@@ -69,9 +69,10 @@ struct Options {
     uint32_t spec_max_games = 96;           // live games up to which a move-step's search runs in tail mode (<= 128 = kTailMaxSlots; beyond 64 a launch has fewer spare rows than games)
     uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
     int free_eval = 1;                      // the free-running search (search_types.h, Free) at free_min_games ... free_max_games live games; 0: one launch per iteration there
-    uint32_t free_min_games = 129, free_max_games = 768;     // (from 129: the plain evaluations of so many boards are of the fused family; <= 1024: k_free_pack runs one thread per game)
+    uint32_t free_min_games = 17, free_max_games = 768;      // (17 ... 40 live games on 64 / 128-row launches of the cluster family, from 41 on the fused family's
+                                                             // 512 / 1024 rows; k_tail keeps <= 16; above 768 the launch per iteration wins; <= 1024: k_free_pack runs one thread per game)
     uint32_t free_rows1024_from = 200;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512 (profiles/r06e_*)
-    uint32_t free_rollout_steps = 12, free_cand_max = 6;     // virtual descents / candidates per game and round at most
+    uint32_t free_rollout_steps = 24, free_cand_max = 12;    // virtual descents / candidates per game and round at most (the candidates follow the spare rows: free_view)
     uint32_t free_iter_cap = 4;             // iterations a game runs in one of its launches at most
     uint32_t free_ring = 128;               // launches whose rows stay in its ring (a row that aged out is evaluated again: same bits)
     uint32_t free_lds_nodes = 3072;         // cap of the tree nodes k_free stages in LDS per game (tests lower it to reach the in-place path)

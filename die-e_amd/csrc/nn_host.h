@@ -28,8 +28,11 @@ struct NetWeights {
     // traffic; its k loop is unrolled in full -- with the loop the accumulators (in AGPRs) were permuted across the back edge, 132
     // v_accvgpr moves per 18 k-steps, which is what "62-67 %" above measured: 603 vs 634 us at 1024 boards, 514 vs 531 at 768.
     // Below ~640 boards (fewer than 160 of 256 CUs busy: no power limit to give back to) the 8-wave geometry 6 is still the faster one.
-    static std::vector<TowerRule> default_tower_table() { return {{928, 5}, {640, 14}, {512, 6}, {256, 10}, {128, 11}}; }   // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
-                                    // pair (257 ... 512 boards) / 2 boards per pair (129 ... 256: 277 ... 298 us against the cluster tower's 313 ... 318)
+    static std::vector<TowerRule> default_tower_table() { return {{928, 5}, {640, 14}, {512, 6}, {256, 10}, {40, 11}}; }   // 10 / 11 = the pair tower (k_tower16p) with 4 boards per
+                                    // pair (257 ... 512 boards) / 2 boards per pair (41 ... 256).  Round 6: the fused family starts at 41 boards, not 129 -- a plain
+                                    // evaluation of 41 ... 128 boards costs ~258 us on the pair tower against 110 ... 172 on the cluster tower, but it happens once per
+                                    // move-step, and it makes the search's launches there 512-row launches of the fused family (the free-running search): 18 ... 33 %
+                                    // faster searches at 48 ... 128 live games (profiles/r06j_*, r06l_*)
     static std::vector<TowerRule> default_tower_table_no_pair() { return {{928, 5}, {640, 14}, {416, 6}, {256, 3}}; }   // option tower_pair = 0 / shared_gpu = 1
     std::vector<TowerRule> tower_table = default_tower_table();      // option "tower_table" (Engine::apply_options)
     DevBuf<uint16_t> pair_ex;       // its exchange buffers (zeroed once)

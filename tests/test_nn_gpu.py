@@ -208,9 +208,13 @@ def test_cluster_tower_two_contexts_on_one_gpu(oracle):
 # The cases are derived from the engine's own dispatch tables (diee_dev_dispatch_bands: one case per band, at the band's largest batch),
 # each case asserts the kernel that really ran (diee_dev_last_dispatch) -- and the bands themselves are pinned here, so that a re-banding
 # of NetWeights::tower_table / cluster_table fails this list instead of silently moving the coverage (round-4 review, weak #2).
-EXPECTED_BANDS = [(1, 32, "k_tower_cl<1, 8>"), (33, 64, "k_tower_cl<2, 8>"), (65, 128, "k_tower_cl<4, 8>"),
-                  (129, 256, "k_tower16p<2, 6>"), (257, 512, "k_tower16p<4, 6>"), (513, 640, "k_tower16<4, 8, 6, 0>"),
+EXPECTED_BANDS = [(1, 32, "k_tower_cl<1, 8>"), (33, 40, "k_tower_cl<2, 8>"),
+                  (41, 256, "k_tower16p<2, 6>"), (257, 512, "k_tower16p<4, 6>"), (513, 640, "k_tower16<4, 8, 6, 0>"),
                   (641, 928, "k_tower16<4, 4, 3, 1>"), (929, 1024, "k_tower16<4, 4, 3, 0>")]
+# round 6 moved the start of the fused family from 129 to 41 boards: k_tower_cl<4, 8> (and <2, 8> above 40 boards) no longer take plain evaluations,
+# but the 128-row launches of a search at 10 ... 40 live games are still theirs -- the round-5 table brings their bands back for their tolerance cases
+ROUND5_TABLE = "928:5,640:14,512:6,256:10,128:11"
+ROUND5_ONLY_BANDS = [(41, 64, "k_tower_cl<2, 8>"), (65, 128, "k_tower_cl<4, 8>")]
 # measured on MI355X (round 2, 1024 mid-game states, random-init seed-0 net): see DESIGN.md section 2; bounds = 3 x measured
 PATH_POLICY_ATOL, PATH_VALUE_ATOL, PATH_POLICY_REL = 2e-5, 8e-3, 0.02
 
@@ -230,13 +234,22 @@ def ref1024(setup, oracle):
     return states, rp, rv
 
 
-@pytest.mark.parametrize("lo,hi,kernel", EXPECTED_BANDS, ids=[k for _, _, k in EXPECTED_BANDS])
+@pytest.mark.parametrize("lo,hi,kernel", EXPECTED_BANDS + ROUND5_ONLY_BANDS, ids=[k for _, _, k in EXPECTED_BANDS] + [k + " (round-5 table)" for _, _, k in ROUND5_ONLY_BANDS])
 def test_every_dispatched_kernel_matches_fp32_on_1024_states(setup, ref1024, lo, hi, kernel):
     """each tower kernel of the dispatch tables evaluates the same 1024 states (in batches of its band's largest size -- and the
     smallest, ragged groups -- so that it is the kernel that runs: asserted through the development probe) and is held to the
     fp32 restatement at the stated tolerance"""
     e, _, _ = setup
     states, rp, rv = ref1024
+    if (lo, hi, kernel) in ROUND5_ONLY_BANDS:
+        e.set_option("tower_table", ROUND5_TABLE)
+    try:
+        _dispatched_kernel_case(e, states, rp, rv, lo, hi, kernel)
+    finally:
+        e.set_option("tower_table", "default")
+
+
+def _dispatched_kernel_case(e, states, rp, rv, lo, hi, kernel):
     for chunk in (hi, lo):
         pol = np.zeros_like(rp); val = np.zeros_like(rv)
         for o in range(0, len(states), chunk):

@@ -297,6 +297,9 @@ def test_growth_workgroups_in_the_cluster_launch_change_nothing(oracle, monkeypa
     _, gcfg = cfgs(oracle, 60)
     gids = np.arange(n, dtype=np.uint32) + 11; rds = np.arange(n, dtype=np.uint32) % 5
     e = diee_amd.Engine(0); e.load_weights(diee_amd.random_weights(0))
+    # (the launch-per-iteration search on the cluster tower, where the growth workgroups live: since round 6 behind the free-running search,
+    # the tail and -- above 40 boards -- the round-5 dispatch table)
+    e.set_options(free_eval=0, spec_eval=0, tower_table="928:5,640:14,512:6,256:10,128:11")
     res = []
     for grow in ("1", "0"):
         e.set_option("cl_grow", grow)

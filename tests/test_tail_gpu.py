@@ -17,6 +17,12 @@ def eng():
     import diee_amd
     e = diee_amd.Engine(0)
     e.load_weights(diee_amd.random_weights(0))
+    # Round 6: by default k_tail keeps the move-steps with at most 16 live games -- the free-running search (tests/test_free_gpu.py) takes 17 ... 768,
+    # and the fused kernel family starts at 41 boards instead of 129.  The looping kernel's whole range (<= 128 games on the cluster family's launches,
+    # 129 ... 256 on the fused family's) stays in the product behind its options and stays held to the oracle here: round 5's dispatch table, free_eval = 0
+    # per case.  (The oracle's evaluator runs on this engine: the same table decides its arithmetic.)
+    e.set_option("tower_table", "928:5,640:14,512:6,256:10,128:11")
+    e.set_option("free_eval", 0)
     yield e
     e.close()
 
@@ -60,11 +66,11 @@ def test_tail_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, quirks):
                        ("launch per iteration", dict(spec_eval=0, spec_rollout_steps=24))):
         # (the default reach is 96 games: the 128-game case asks for the kernel's whole range; from 129 games on the free-running search
         # takes a move-step by default since round 6 -- tests/test_free_gpu.py --: off here, so that k_tail's fused-family launches stay held to the oracle)
-        eng.set_options(spec_max_games=128, free_eval=0, **opts)
+        eng.set_options(spec_max_games=128, **opts)
         try:
             res[name] = eng.alpha_mcts_parallel(states, gcfg, SEED, 9, gids, rds, ref_quirks=bool(quirks))
         finally:
-            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96, spec_child_rows=CHILD_ROWS, free_eval=1)
+            eng.set_options(spec_eval=1, spec_rollout_steps=24, spec_max_games=96, spec_child_rows=CHILD_ROWS)
     os_ = ostats.as_dict()
     for name, r in res.items():
         assert r["probs"].tobytes() == probs.tobytes(), (name, np.abs(np.nan_to_num(r["probs"]) - np.nan_to_num(probs)).max())
