@@ -13,7 +13,7 @@ _Static_assert(sizeof(diee_mcts_cfg) == 20, "diee_mcts_cfg is 5 x 4 bytes");
 _Static_assert(offsetof(diee_mcts_cfg, c) == 4 && offsetof(diee_mcts_cfg, round_limit) == 8 &&
                offsetof(diee_mcts_cfg, dir_alpha) == 12 && offsetof(diee_mcts_cfg, dir_eps) == 16, "diee_mcts_cfg fields");
 _Static_assert(sizeof(diee_batch) == 16 && offsetof(diee_batch, first_game_id) == 4 && offsetof(diee_batch, seed) == 8, "diee_batch");
-_Static_assert(sizeof(diee_stats) == (29 + 27 + 3) * 8, "diee_stats is 59 x 8 bytes");
+_Static_assert(sizeof(diee_stats) == (29 + 27 + 3 + 9) * 8, "diee_stats is 68 x 8 bytes");
 _Static_assert(sizeof(diee_fragments) == 8 + 4 * sizeof(void*), "diee_fragments");
 
 #define F(T, f) printf("  \"%s.%s\": %zu,\n", #T, #f, offsetof(T, f))

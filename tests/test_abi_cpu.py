@@ -57,7 +57,7 @@ def test_header_compiles_as_c_and_layouts_match_the_ctypes_mirror(tmp_path):
             continue
         assert getattr(mirrors[st], field).offset == off, key
         seen += 1
-    assert seen == 35 + 5 + 3
+    assert seen == 35 + 5 + 3 + 1                      # (+ band_flops_demanded, round 6)
     assert [n for n, _ in diee_amd.Stats._fields_] == [k.split(".")[1] for k in doc if k.startswith("diee_stats.")]
 
 
