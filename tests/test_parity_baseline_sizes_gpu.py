@@ -102,10 +102,22 @@ def test_mcts_batch_bit_exact_config4_1024x1600(eng, oracle):
 @pytest.mark.parametrize("quirks", [1, 0])
 @pytest.mark.parametrize("n,iters", [(900, 100), (600, 40), (300, 40)], ids=["900x100", "600x40", "300x40"])
 def test_compacted_evaluation_bit_exact_vs_oracle(eng, oracle, n, iters, quirks):
-    """257 ... 928 roots: the engine evaluates only the slots whose selected leaf is not terminal (row map built on the
-    device, up to three tower launches that size themselves from it), the oracle pushes every slot like the reference"""
-    roots, probs, os_, r = run_both(eng, oracle, mixed_roots(oracle, n), iters, quirks, step=3)
+    """257 ... 928 roots on the launch-per-iteration search (since round 6: 769 ... 928 by default, below behind free_eval = 0): the engine
+    evaluates only the slots whose selected leaf is not terminal (row map built on the device, up to three tower launches that size
+    themselves from it), the oracle pushes every slot like the reference.  With the default dispatch 600 and 300 roots take the
+    free-running search -- held to the same oracle run, rows counted its way."""
+    states = mixed_roots(oracle, n)
+    roots, probs, os_, r = run_both(eng, oracle, states, iters, quirks, step=3)
     assert_search_equal(roots, probs, os_, r)
+    if n <= 768:
+        assert r["stats"]["tail_iterations"] == iters            # the free-running search ran
+        eng.set_option("free_eval", 0)
+        try:
+            _, _, _, r = run_both(eng, oracle, states, iters, quirks, step=3)
+        finally:
+            eng.set_option("free_eval", 1)
+        assert_search_equal(roots, probs, os_, r)
+    assert r["stats"]["tail_iterations"] == 0
     assert r["stats"]["nn_rows"] < r["stats"]["nn_evals"]        # the compaction really skipped rows ...
     assert r["stats"]["nn_rows"] >= r["stats"]["nn_evals"] - os_["terminal_hits"]      # ... at most one per terminal selection
 
