@@ -1249,7 +1249,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     FR_STAMP(0);
     bool have = false, stalled = false;
     uint32_t minprog = 0;                                       // a lower bound of the batch's progress (every game has published iteration 0's selection)
-    for (uint32_t ran = 0;; ++ran) {
+    uint32_t ran = 0;
+    for (;; ++ran) {
         const uint32_t cr = lterm ? 0u : crow_of(leaf);
         have = lterm || at_hand(cr);
         if (!have) break;
@@ -1463,7 +1464,10 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         // its value, a finished game as +-1 for the root's player -- end on, in the order they are found (= the order the search will want them) ----
         uint32_t* wl = F.wish + (size_t)slot * kFreeWish;
         if (dem) { if (lane == 0) wl[0] = leaf; nw = 1; }
-        const uint32_t want = F.cand_max < kFreeWish - 1u ? F.cand_max : kFreeWish - 1u;
+        // (the launch lasts as long as its busiest game: one that ran its full share of iterations -- it is ahead of the others and the rows it was
+        // granted served it well -- looks for fewer candidates: every iteration it ran takes two virtual descents off its budget)
+        const uint32_t want0 = F.cand_max < kFreeWish - 1u ? F.cand_max : kFreeWish - 1u;
+        const uint32_t want = want0 > ran / 2u + 1u ? want0 - ran / 2u : (want0 ? 1u : 0u);
         uint32_t ncand = 0;
         if (want > 0 && F.rollout_steps > 0) {
             const uint32_t nu = used < ln ? used : ln;
