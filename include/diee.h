@@ -170,14 +170,17 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  * for the two tables "a:b,c:d" | "none" | "default").  The environment is NOT consulted by any call below: it is read once, inside
  * diee_create, as a development override of the defaults (DIEE_<KEY IN CAPITALS>); a host sets what it needs through this call.
  *   shared_gpu            0 | 1   another PROCESS computes on this GPU (several ranks per GPU): the kernels whose workgroups wait
- *                                 for each other inside a launch (cluster tower <= 256 boards, pair tower 129 ... 512) are not used;
- *                                 the caller's training step does the same with diee_train_set_bn_coop(0).  Default 0.
+ *                                 for each other inside a launch (cluster tower <= 40 boards, pair tower 41 ... 512, the looping tree kernel
+ *                                 of a batch's last 16 games: one workgroup per game, each alone on its compute unit -- also refused on a
+ *                                 device with fewer compute units than games) are not used; the caller's training step does the same with
+ *                                 diee_train_set_bn_coop(0).  Default 0.
  *   tower_pair            0 | 1   the pair tower alone
  *   tower_cl              "max_boards:boards_per_cluster,..."   the cluster tower's table ("none": per-layer kernels below 257 boards)
  *   tower_table           "min_boards:geometry,..."             the fused tower's table (development)
  *   compact               0 | 1   above 256 live games evaluate only the slots whose leaf needs it (default 1; 0 = every row, like the reference)
  *   spec_eval             0 | 1   speculative leaf evaluation in the free rows of the launches of a batch's tail (default 1; same results)
- *   spec_max_games        live games (all batches of the call) up to which a move-step's search runs that way (default 96, at most 128)
+ *   spec_max_games        live games (all batches of the call) up to which a move-step's search runs that way (default 96, at most 128) -- where the
+ *                                 free-running search below does not take the move-step first (by default it takes 17 ... 768 live games)
  *   spec_rows64_from, spec_rows128_from   live games from which a tail launch carries 64 / 128 rows instead of 32 (defaults 5 / 10)
  *   spec_extra_rows       candidates a game may find beyond its share of a tail launch whose rows are scarce: they take what other games leave free (default 2)
  *   spec_child_rows       children of a leaf that waits for its evaluation that are evaluated in the same tail launch at most (default 16; 0: off)
