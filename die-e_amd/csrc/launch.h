@@ -74,6 +74,10 @@ void launch_policy_fc(hipStream_t st, const uint16_t* hp, const void* wpack, con
 void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, int n_upper, const void* states,
                           const void* winit16, const float* binit, const void* whead16, const float* bhead, uint16_t* hp, float* hv,
                           const uint32_t* row_slot, const uint32_t* n_rows, uint16_t* pair_ex = nullptr, uint32_t* err = nullptr);
+// the same for a round of the free-running search (<= 1024 rows gathered from the tree arena by index): two launches, one with work
+void launch_tower_free(hipStream_t st, const void* wt16, const float* bias, int n_upper, const void* states, const void* winit16, const float* binit,
+                       const void* whead16, const float* bhead, uint16_t* hp, float* hv, const uint32_t* row_idx, const uint32_t* n_rows,
+                       uint16_t* pair_ex = nullptr, uint32_t* err = nullptr);
 // pair tower (k_tower16p): the fused tower with 4 boards per PAIR of workgroups, 257 ... 512 boards; `ex` = tower_pair_exchange_bytes()
 // of zeroed device memory, `err` gets bit 2 set if a hand-over timed out.  false = too many boards.
 // the 4-board pair tower over the first *n_rows (counted on the device, <= G) of G dense rows: a tail launch at 129 ... 256 live games
@@ -100,7 +104,7 @@ void launch_tail(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
 // lists its wishes; k_free_pack grants the rows of tower launch q
 void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, uint32_t n, const SearchParams& P, float c, const Free& F, uint32_t q);
 uint32_t free_lds_nodes_for(uint32_t n, uint32_t cus);      // nodes of a game's tree k_free stages in LDS when n games share `cus` CUs
-void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G);
+void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G, unsigned long long* step_log = nullptr, uint32_t step = 0);
 // rows of the next network evaluation: the slots with skip[slot] == 0, in slot order (row_slot / slot_row / *n_rows; the
 // count also goes to rows_log[log_idx])
 void launch_row_map(hipStream_t st, const uint8_t* skip, uint32_t n, uint32_t* row_slot, uint32_t* slot_row, uint32_t* n_rows,

@@ -1249,9 +1249,20 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     FR_STAMP(0);
     bool have = false, stalled = false;
     uint32_t minprog = 0;                                       // a lower bound of the batch's progress (every game has published iteration 0's selection)
+    // the selected leaf's network row -- 22 logits per lane, the value features -- is requested as soon as the leaf is known (here, and
+    // behind every selection below): the round trip to where the tower launch left it passes under the flag words and the loop's bookkeeping
+    auto net_row = [&](uint32_t cr_) {
+        NetRowLoaded p;
+        const size_t ring = (size_t)(((cr_ - 1u) >> kFreeRowBits) % F.ring) * F.rows + ((cr_ - 1u) & ((1u << kFreeRowBits) - 1u));
+        p.vh = value_head_load(F.hv + ring * 72, S.wv, lane);
+        softmax_load(F.logits + ring * 1352, lane, p.lg);
+        return p;
+    };
+    uint32_t cr = lterm ? 0u : crow_of(leaf);
+    NetRowLoaded pre;
+    if (!lterm && at_hand(cr)) pre = net_row(cr);
     uint32_t ran = 0;
     for (;; ++ran) {
-        const uint32_t cr = lterm ? 0u : crow_of(leaf);
         have = lterm || at_hand(cr);
         if (!have) break;
         if (ran >= F.iter_cap) { stalled = true; break; }       // (enough for this launch: the other games' workgroups are done long since)
@@ -1277,13 +1288,6 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             if (!fin) { stalled = true; break; }
         }
         FR_STAMP(1);
-        const NetRowLoaded pre = [&] {
-            NetRowLoaded p;
-            const size_t ring = lterm ? 0u : (size_t)(((cr - 1u) >> kFreeRowBits) % F.ring) * F.rows + ((cr - 1u) & ((1u << kFreeRowBits) - 1u));
-            p.vh = value_head_load(F.hv + ring * 72, S.wv, lane);
-            softmax_load(F.logits + ring * 1352, lane, p.lg);
-            return p;
-        }();
         // ================= iteration `it` (expand_body<false, 0>'s operations, in its order) =================
         const bool active = ifl.x != 0u;
         float v = 0.0f;
@@ -1433,6 +1437,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 sel = node;
                 lst = load_state(&T.state[base + node]);
             }
+            cr = lterm ? 0u : crow_of(leaf);
+            if (!lterm && at_hand(cr)) pre = net_row(cr);       // (in flight while the selection is published)
         }
         ++it;
         __syncthreads();
@@ -1596,7 +1602,9 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
 }
 
 // fold the per-slot counters of one move-step into the totals of each batch (one block per batch)
-__global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
+// step_log (may be null): [2 * step] += the move-step's expansions, [2 * step + 1] += the rows it evaluated -- the share of a launch's rows the
+// search went on to USE is known only when its search is over; the bench's bands weigh a sampled launch by its move-step's share
+__global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G, unsigned long long* step_log, uint32_t step) {
     __shared__ unsigned long long part[SC_COUNT][4];
     const uint32_t seg = blockIdx.x;
     const uint32_t s0 = G.first_slot[seg], s1 = G.end_slot[seg];
@@ -1629,6 +1637,8 @@ __global__ __launch_bounds__(256) void k_reduce_counters(Slots S, Segs G) {
             for (int w = 0; w < 4; ++w) t = c == SC_MAX_CHILDREN ? (part[c][w] > t ? part[c][w] : t) : t + part[c][w];
             if (c == SC_MAX_CHILDREN) { if (t > cnt[map[c]]) cnt[map[c]] = t; }
             else cnt[map[c]] += t;
+            if (step_log && c == SC_EXPANSIONS) atomicAdd(&step_log[2 * (size_t)step], t);
+            if (step_log && c == SC_NN_ROWS) atomicAdd(&step_log[2 * (size_t)step + 1], t);
         }
     }
 }
@@ -1982,8 +1992,8 @@ void launch_free(hipStream_t st, const Tree& T, const Slots& S, const Segs& G, u
     hipLaunchKernelGGL(k_free, dim3(n), dim3(64), free_lds_bytes(F.lds_nodes), st, T, S, G, n, P, c, FreeArgs{F, q});
     hipLaunchKernelGGL(k_free_pack, dim3(1), dim3(1024), 0, st, F, n, T.node_cap, q, T.state);
 }
-void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G) {
-    hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G);
+void launch_reduce_counters(hipStream_t st, const Slots& S, const Segs& G, unsigned long long* step_log, uint32_t step) {
+    hipLaunchKernelGGL(k_reduce_counters, dim3(G.n), dim3(256), 0, st, S, G, step_log, step);
 }
 void launch_row_map(hipStream_t st, const uint8_t* skip, uint32_t n, uint32_t* row_slot, uint32_t* slot_row, uint32_t* n_rows,
                     uint32_t* rows_log, uint32_t log_idx) {

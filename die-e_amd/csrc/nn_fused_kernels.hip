@@ -276,6 +276,7 @@ __global__ __launch_bounds__(64 * NW) void k_tower16(const uint16_t* __restrict_
         const int rest = nr - main_b;
         int lo, hi;
         if (rm.mode == 1) { lo = 0; hi = main_b; }
+        else if (rm.mode == 4) { lo = 0; hi = nr > kRemSplit ? nr : 0; }        // a free-running round of up to one pass: every row, unless the pair tower's launch takes them (mode 3)
         else if (rm.mode == 2) { lo = main_b; hi = rest > kRemSplit ? nr : main_b; }
         else { lo = main_b; hi = rest <= kRemSplit ? nr : main_b; }
         board0 += lo;
@@ -561,6 +562,20 @@ void launch_tower_compact(hipStream_t st, const void* wt16, const float* bias, i
     else
         tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max < kRemSplit ? rest_max : kRemSplit, states, winit16,
                                 binit, whead16, bhead, hp, hv, RowMap{row_slot, n_rows, 3, main_cap});
+}
+// A round of the free-running search (search_types.h, Free): up to n_upper <= 1024 rows gathered by index, their number on the device.  TWO launches,
+// one of which has work: the one-pass geometry when there are more than kRemSplit rows (the part-filled instantiation is the same code: no third launch
+// whose workgroups would only look at the count and leave, ~5 us a round), else the pair tower.
+void launch_tower_free(hipStream_t st, const void* wt16, const float* bias, int n_upper, const void* states, const void* winit16, const float* binit,
+                       const void* whead16, const float* bhead, uint16_t* hp, float* hv, const uint32_t* row_idx, const uint32_t* n_rows, uint16_t* pair_ex, uint32_t* err) {
+    if (n_upper > kRemSplit)
+        tower16_launch<4, 4, 3>(st, nullptr, wt16, bias, nullptr, n_upper < kFullChip ? n_upper : kFullChip, states, winit16, binit, whead16, bhead, hp, hv,
+                                RowMap{row_idx, n_rows, 4, 0});
+    const int rest_max = n_upper < kRemSplit ? n_upper : kRemSplit;
+    if (pair_ex)
+        launch_tower_pair_rows(st, wt16, bias, rest_max, states, winit16, binit, whead16, bhead, hp, hv, pair_ex, err, RowMap{row_idx, n_rows, 3, 0});
+    else
+        tower16_launch<2, 8, 9>(st, nullptr, wt16, bias, nullptr, rest_max, states, winit16, binit, whead16, bhead, hp, hv, RowMap{row_idx, n_rows, 3, 0});
 }
 // The geometries of the fused tower (wt16 = 16-column fragments, 16x16x32 MFMA).  PRODUCT build -- what the dispatch tables and their
 // fallbacks launch: 5 = 4 boards x 4 waves (one per SIMD, k loop unrolled) for one pass of the chip, 14 = the same code instantiated

@@ -567,7 +567,7 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
     if (sample) {
         if (ok) {
             HIPCHK(hipEventRecord(ev1, e.stream));
-            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 2, (int)seq, boards_band, n_dem_dev ? (int)seq : -1});      // flops per ROW; a launch without rows is dropped at the harvest
+            W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 2, (int)seq, boards_band, n_dem_dev ? (int)seq : -1, W.cur_step});      // flops per ROW; a launch without rows is dropped at the harvest
         } else { W.free_events.push_back(ev0); W.free_events.push_back(ev1); }
     }
     return ok;
@@ -578,6 +578,7 @@ bool nn_forward_tail(Engine& e, const void* states_dev, int G_upper, const uint3
 // launches (launch_tower_compact: one pass of the chip for 929 ... 1024 rows, the part-filled instantiation or the pair tower below) + the
 // policy FC, outputs straight into the caller's ring rows.  Every launch is of the fused 16x16x32 family: a row's bits are those of a plain
 // evaluation of more than 128 boards, whichever launch computes it.
+constexpr int kFreeOnePass = 1024;
 bool nn_free_available(Engine& e, int n) {
     if (!e.net || !e.net->loaded) return false;
     const NetWeights& W = *e.net;
@@ -599,13 +600,17 @@ void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_i
     }
     uint16_t* pex = pair_exchange(e);
     if (pex) W.cluster_used = true;                                 // (the pair tower's hand-overs report through the starved-hand-over bit)
-    launch_tower_compact(st, W.wtower16.p, W.btower.p, rows_upper, arena_states, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
-                         W.hp.p, hv_out, rows_idx, n_rows_dev, pex, e.flags_dev.p);
+    if (rows_upper <= kFreeOnePass)
+        launch_tower_free(st, W.wtower16.p, W.btower.p, rows_upper, arena_states, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
+                          W.hp.p, hv_out, rows_idx, n_rows_dev, pex, e.flags_dev.p);
+    else
+        launch_tower_compact(st, W.wtower16.p, W.btower.p, rows_upper, arena_states, W.winit16.p, W.bconv[0].p, W.whead16.p, W.bconv[39].p,
+                             W.hp.p, hv_out, rows_idx, n_rows_dev, pex, e.flags_dev.p);
     W.last_dispatch.clear();
     W.last_dispatch.push_back({1, -1, rows_upper});
     if (sample) {
         HIPCHK(hipEventRecord(ev1, st));
-        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, boards_band, n_dem_dev ? (int)seq : -1});     // flops per ROW; a launch without rows is dropped at the harvest
+        W.pending.push_back({ev0, ev1, 38.0 * 2.0 * 24.0 * 2304.0 * 256.0, 1, 1, (int)seq, boards_band, n_dem_dev ? (int)seq : -1, W.cur_step});     // flops per ROW; a launch without rows is dropped at the harvest
     }
     fc_launch(e, W.hp.p, logits_out, rows_upper, n_rows_dev);
 }
@@ -675,7 +680,7 @@ NetHeads nn_heads(Engine& e, int G) {
 }
 
 // harvest sampled conv timings (call after a stream sync)
-void nn_harvest(Engine& e, diee_stats* stats) {
+void nn_harvest(Engine& e, diee_stats* stats, const std::vector<unsigned long long>* step_log) {
     if (!e.net) return;
     NetWeights& W = *e.net;
     std::vector<uint32_t> rows_log, dem_log;
@@ -689,10 +694,17 @@ void nn_harvest(Engine& e, diee_stats* stats) {
     }
     for (auto& p : W.pending) {
         float ms = 0.f;
-        double flops_dem = p.flops;                                                 // (a plain or compacted evaluation: every row was asked for)
-        if (p.dem_seq >= 0) flops_dem = p.flops * (double)dem_log[(size_t)p.dem_seq];
-        else if (p.rows_seq >= 0) flops_dem = p.flops * (double)rows_log[(size_t)p.rows_seq];
         if (p.rows_seq >= 0) p.flops *= (double)rows_log[(size_t)p.rows_seq];      // compacted batch: flops per row x rows evaluated
+        // the rows the SEARCH used: every row of a plain or compacted evaluation; of a tail / free-running launch (rows evaluated ahead of the
+        // search: which of them it goes on to expand is known only afterwards) the share its move-step's search used, expansions / rows evaluated
+        double flops_dem = p.flops;
+        if (p.dem_seq >= 0) {
+            double share = 0.0;
+            if (step_log && p.step >= 0 && 2 * (size_t)p.step + 1 < step_log->size() && (*step_log)[2 * (size_t)p.step + 1] > 0)
+                share = std::min(1.0, (double)(*step_log)[2 * (size_t)p.step] / (double)(*step_log)[2 * (size_t)p.step + 1]);
+            else if (rows_log[(size_t)p.rows_seq] > 0) share = std::min(1.0, (double)dem_log[(size_t)p.dem_seq] / (double)rows_log[(size_t)p.rows_seq]);   // (no log: the rows demanded when it was launched)
+            flops_dem = p.flops * share;
+        }
         const bool empty = p.rows_seq >= 0 && rows_log[(size_t)p.rows_seq] == 0;   // (a tail launch sent ahead of a search that was complete already)
         if (!empty && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             if (p.kind == 1 || p.kind == 3) {

@@ -76,11 +76,12 @@ struct NetWeights {
     DevBuf<float> hv, logits;
     int cap_games = 0;
     // sampled HIP-event timing of the tower conv kernel
-    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; int boards; int dem_seq = -1; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
+    struct Pending { hipEvent_t a, b; double flops; int launches; int kind; int rows_seq; int boards; int dem_seq = -1; int step = -1; };   // kind 0 per-layer, 1 fused tower (> 256 boards), 3 fused tower as one <4,8,3> launch, 2 small batch (<= 256 boards: cluster tower, two-board pair tower)
                                     // tower; rows_seq >= 0: flops is per row, the row count of that (compacted) launch sits in rows_log[rows_seq]
     bool compact = true;            // search iterations above compact_above live games evaluate only the slots that need it (k_row_map)
     int compact_above = 256;        // (below, the batch is latency-bound and runs whole on the cluster tower)
     DevBuf<uint32_t> rows_log;      // [kRowsLog] rows evaluated by the compacted forward number (forward_count mod kRowsLog)
+    int cur_step = -1;              // the move-step whose search is being enqueued (search_host.cpp; -1: none): a sampled launch remembers it
     DevBuf<uint32_t> dem_log;       // [kRowsLog] ... of which DEMANDED by the search (tail / free-running launches: the others are speculative)
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
@@ -126,7 +127,9 @@ void nn_forward_free(Engine& e, const void* arena_states, const uint32_t* rows_i
 bool nn_cluster_used(Engine& e);
 void nn_disable_cluster(Engine& e);
 void nn_reset_cluster(Engine& e);
-void nn_harvest(Engine& e, diee_stats* stats);
+// step_log (host copy, may be empty): per move-step { expansions, rows evaluated }: a sampled launch counts towards band_flops_demanded with the share of its
+// move-step's rows that the search used
+void nn_harvest(Engine& e, diee_stats* stats, const std::vector<unsigned long long>* step_log = nullptr);
 void nn_reset_timing(Engine& e);
 void nn_conv_bench(Engine& e, int G, int variant, int reps, float* us_mode0, float* us_mode1, float* us_forward);
 

@@ -36,6 +36,8 @@ struct SearchBufs {
     DevBuf<unsigned long long> counters, counters_bak;
     DevBuf<uint32_t> slot_cnt;
     uint32_t iter_cap = 0;
+    DevBuf<unsigned long long> step_log;                       // [2 * kStepLog] per move-step { expansions, rows evaluated } (k_reduce_counters)
+    uint32_t cur_step = 0;
     // the tail of a batch (search_types.h, Tail)
     DevBuf<uint32_t> tl_crow, tl_rows_node, tl_words;          // tl_words = n_rows[launches] ++ state[4] ++ bar[2 * launches + 8] ++ bar2[launches] ++ n_dem[launches]
     DevBuf<float> tl_cval, tl_logits, tl_hv;
@@ -193,6 +195,7 @@ void dirichlet_host(uint64_t seed, uint32_t step, float alpha, int n, float* out
 }
 namespace {
 
+constexpr uint32_t kStepLog = 2048;                          // move-steps of a call with a log entry of their own (later ones share the last)
 constexpr uint32_t kLiveWords = 1 + 4 * kMaxSegments;        // DeliverSummary at its largest; live_host[kLiveWords] = the flag word
 
 void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
@@ -222,6 +225,7 @@ void reserve_search(Engine& e, uint32_t slots, uint32_t iterations) {
         HIPCHK(hipHostMalloc((void**)&B.noise_host, sizeof(float) * 2 * kMaxSegments * 1352));
         HIPCHK(hipHostMalloc((void**)&B.live_host, sizeof(uint32_t) * (kLiveWords + 1)));
     }
+    if (!B.step_log.p) B.step_log.ensure(2 * (size_t)kStepLog);
     if (iterations + 1 > B.iter_cap) { B.iter_flags.ensure((size_t)kMaxSegments * 2 * ((size_t)iterations + 1)); B.iter_cap = iterations + 1; }
 }
 
@@ -486,14 +490,14 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
     if (free_possible(e, n, cfg)) {                                  // 129 ... 768 live games: every game on its own iteration counter
         S.slot_row = nullptr;
         free_run(e, n, T, S, G, cfg, P);
-        launch_reduce_counters(st, S, G);
+        launch_reduce_counters(st, S, G, B.step_log.p, std::min(B.cur_step, kStepLog - 1));
         HIPCHK(hipGetLastError());
         return;
     }
     if (tail_possible(e, n, cfg)) {                                  // <= 96 live games: the games in lockstep inside one launch
         S.slot_row = nullptr;
         tail_run(e, n, T, S, G, cfg, P);
-        launch_reduce_counters(st, S, G);
+        launch_reduce_counters(st, S, G, B.step_log.p, std::min(B.cur_step, kStepLog - 1));
         HIPCHK(hipGetLastError());
         return;
     }
@@ -502,7 +506,7 @@ void mcts_run(Engine& e, uint32_t n, uint32_t n_segs, const diee_mcts_cfg& cfg, 
         S.slot_row = compacted ? B.slot_row.p : nullptr;
         launch_expand(st, T, S, G, n, it, P, it + 1 < cfg.iterations ? it + 1 : kNoNextIteration, cfg.c, grown, xv);
     }
-    launch_reduce_counters(st, S, G);
+    launch_reduce_counters(st, S, G, B.step_log.p, std::min(B.cur_step, kStepLog - 1));
     HIPCHK(hipGetLastError());
 }
 
@@ -598,6 +602,8 @@ void Engine::mcts_batch(const diee_bg_state* roots, uint32_t n, const diee_mcts_
     const int se = net->sample_every; net->sample_every = 0;
     draw_noise(B, 0, one, step, cfg->dir_alpha);
     B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0; B.fr_prev_need = 0;
+    HIPCHK(hipMemsetAsync(B.step_log.p, 0, sizeof(unsigned long long) * 2 * kStepLog, stream));
+    B.cur_step = 0; net->cur_step = 0;
     mcts_run(*this, n, 1, *cfg, 0, flags);
     if (cluster_starved(*this)) {                                   // repeat on the per-layer kernels
         HIPCHK(hipMemsetAsync(B.counters.p, 0, sizeof(unsigned long long) * CNT_COUNT, stream));
@@ -732,6 +738,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
 
     upload_segments(*this, bt);
     B.tl_iterations = B.tl_launched = B.tl_with_rows = B.tl_spec_rows = B.tl_syncs = 0; B.tl_prev_need = 0; B.fr_prev_need = 0;
+    HIPCHK(hipMemsetAsync(B.step_log.p, 0, sizeof(unsigned long long) * 2 * kStepLog, stream));
     nn_reset_timing(*this);
     launch_init_games(stream, Gm, G, n_games);
     draw_noise(B, 0, bt, 0, cfg->dir_alpha);
@@ -750,6 +757,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
         HIPCHK(hipMemsetAsync(B.seg_slots.p, 0, sizeof(uint32_t) * 2 * kMaxSegments, stream));
         launch_gather_roots(stream, Gm, S, G, n_live);
         HIPCHK(hipMemcpyAsync(B.counters_bak.p, B.counters.p, sizeof(unsigned long long) * CNT_COUNT * n_batches, hipMemcpyDeviceToDevice, stream));
+        B.cur_step = step; net->cur_step = (int)std::min(step, kStepLog - 1);
         mcts_run(*this, n_live, n_batches, *cfg, buf, flags);           // :146
         // while the GPU searches: the next move-step's Dirichlet samples (the only host arithmetic of a move-step) and the
         // previous move-step's records (enqueued behind this step's search so that the search never waits for the host)
@@ -780,8 +788,12 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     check_overflow();
+    std::vector<unsigned long long> step_log(2 * (size_t)kStepLog);
+    d2h(step_log.data(), B.step_log.p, step_log.size());
+    sync();
+    net->cur_step = -1;
     if (stats) {
-        nn_harvest(*this, &stats[0]);                                   // sampled tower timings: whole call, reported with batch 0
+        nn_harvest(*this, &stats[0], &step_log);                        // sampled tower timings: whole call, reported with batch 0
         for (uint32_t k = 0; k < n_batches; ++k) {
             read_counters(*this, k, &stats[k]);
             stats[k].move_steps = steps_of[k]; stats[k].seconds = secs; stats[k].fragments = frag_total[k];
@@ -789,7 +801,7 @@ void Engine::self_play_multi(const diee_batch* batches, uint32_t n_batches, cons
         stats[0].deliver_seconds = deliver_secs; stats[0].deliver_bytes = deliver_bytes;
         stats[0].tail_iterations = B.tl_iterations; stats[0].tail_launches = B.tl_with_rows; stats[0].tail_spec_rows = B.tl_spec_rows;
     } else {
-        nn_harvest(*this, nullptr);
+        nn_harvest(*this, nullptr, &step_log);
     }
     if (deliver)
         for (uint32_t k = 0; k < n_batches; ++k) fb[k].release(&outs[k]);

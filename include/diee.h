@@ -135,8 +135,8 @@ typedef struct {
     uint64_t tail_iterations;  /* (round 6: the iterations, launches and speculative rows of the free-running search at 257 ... 768 live games count here too) */
     uint64_t tail_launches;
     uint64_t tail_spec_rows;
-    /* band_flops without the rows evaluated on speculation: the FLOPs of the rows the search asked for (the demanded leaves of a tail /
-     * free-running launch; every row of a plain or compacted evaluation) */
+    /* band_flops without the rows evaluated in vain: every row of a plain or compacted evaluation; of a tail / free-running launch -- whose rows
+     * are evaluated ahead of the search -- the share its move-step's search went on to use (expansions / rows evaluated of that move-step) */
     double   band_flops_demanded[9];
 } diee_stats;
 
