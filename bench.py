@@ -745,9 +745,11 @@ def main(argv=None, engine_factory=None):
                       "tree_nodes_per_search": tot["children"] / max(tot["plies"], 1) + 1,
                       "tree_bytes_per_search": 56 * (tot["children"] / max(tot["plies"], 1) + 1),
                       "tree_arena_bytes_per_game": 56 * ((args.iterations + 1) * 128 + 64),
-                      # the tail of a batch (<= 96 live games: die-e_amd/csrc/search_types.h Tail): search iterations the looping tree kernel ran,
-                      # the network launches they needed (one per iteration without it) and the rows evaluated on speculation, per batch
-                      "tail": {"iterations_per_step": tot.get("tail_iterations", 0) / max(args.steps, 1) / world,
+                      # the free-running search and the tail of a batch (die-e_amd/csrc/search_types.h Free, Tail): search iterations they ran,
+                      # the network launches they needed (one per iteration without them) and the rows evaluated ahead of the search, per batch
+                      "tail": {"what": "search iterations that ran outside the launch-per-iteration search -- the free-running search (17 ... 800 live games, round 6) and the looping "
+                                       "kernel k_tail (<= 16) --, the network launches they needed, the rows of those launches that no game was waiting for when they went out",
+                               "iterations_per_step": tot.get("tail_iterations", 0) / max(args.steps, 1) / world,
                                "launches_per_step": tot.get("tail_launches", 0) / max(args.steps, 1) / world,
                                "speculative_rows_per_step": tot.get("tail_spec_rows", 0) / max(args.steps, 1) / world,
                                "launches_per_iteration": tot.get("tail_launches", 0) / max(tot.get("tail_iterations", 0), 1)}},

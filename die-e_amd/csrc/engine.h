@@ -69,8 +69,8 @@ struct Options {
     uint32_t spec_max_games = 96;           // live games up to which a move-step's search runs in tail mode (<= 128 = kTailMaxSlots; beyond 64 a launch has fewer spare rows than games)
     uint32_t spec_rows64_from = 5, spec_rows128_from = 10;      // live games from which a tail launch carries 64 / 128 rows instead of 32
     int free_eval = 1;                      // the free-running search (search_types.h, Free) at free_min_games ... free_max_games live games; 0: one launch per iteration there
-    uint32_t free_min_games = 17, free_max_games = 768;      // (17 ... 40 live games on 64 / 128-row launches of the cluster family, from 41 on the fused family's
-                                                             // 512 / 1024 rows; k_tail keeps <= 16; above 768 the launch per iteration wins; <= 1024: k_free_pack runs one thread per game)
+    uint32_t free_min_games = 17, free_max_games = 800;      // (17 ... 40 live games on 64 / 128-row launches of the cluster family, from 41 on the fused family's
+                                                             // 512 / 1024 rows; k_tail keeps <= 16; above ~820 the launch per iteration wins (profiles/r06r_*); <= 1024: k_free_pack runs one thread per game)
     uint32_t free_rows1024_from = 200;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512 (profiles/r06e_*)
     uint32_t free_rollout_steps = 24, free_cand_max = 12;    // virtual descents / candidates per game and round at most (the candidates follow the spare rows: free_view)
     uint32_t free_cand_x4 = 8;              // candidates per game and round = 1 + this / 4 x the spare rows per game (8: twice the rows a game can hope for)

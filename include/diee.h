@@ -132,7 +132,7 @@ typedef struct {
     /* the tail of a batch (<= spec_max_games = 96 and 129 ... spec_fused_games = 256 live games; option spec_eval): search iterations run by the looping tree kernel, the network launches
      * they needed (one per iteration without it), and the rows those launches evaluated on speculation (all batches of the call,
      * reported with batch 0) */
-    uint64_t tail_iterations;  /* (round 6: the iterations, launches and speculative rows of the free-running search at 257 ... 768 live games count here too) */
+    uint64_t tail_iterations;  /* (round 6: the iterations, launches and speculative rows of the free-running search at 17 ... 800 live games count here too) */
     uint64_t tail_launches;
     uint64_t tail_spec_rows;
     /* band_flops without the rows evaluated in vain: every row of a plain or compacted evaluation; of a tail / free-running launch -- whose rows
@@ -180,13 +180,13 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *   compact               0 | 1   above 256 live games evaluate only the slots whose leaf needs it (default 1; 0 = every row, like the reference)
  *   spec_eval             0 | 1   speculative leaf evaluation in the free rows of the launches of a batch's tail (default 1; same results)
  *   spec_max_games        live games (all batches of the call) up to which a move-step's search runs that way (default 96, at most 128) -- where the
- *                                 free-running search below does not take the move-step first (by default it takes 17 ... 768 live games)
+ *                                 free-running search below does not take the move-step first (by default it takes 17 ... 800 live games)
  *   spec_rows64_from, spec_rows128_from   live games from which a tail launch carries 64 / 128 rows instead of 32 (defaults 5 / 10)
  *   spec_extra_rows       candidates a game may find beyond its share of a tail launch whose rows are scarce: they take what other games leave free (default 2)
  *   spec_child_rows       children of a leaf that waits for its evaluation that are evaluated in the same tail launch at most (default 16; 0: off)
  *   spec_fused_games      129 ... this many live games search that way too, on 512-row launches of the fused kernel family (default 256 = at most; 0: off)
- *   free_eval             0 | 1   the free-running search at free_min_games ... free_max_games live games (defaults 257 ... 768; at most 1024): every
- *                                 game keeps its own iteration counter, a launch of 512 / 1024 rows (free_rows1024_from, default 449 games) carries the
+ *   free_eval             0 | 1   the free-running search at free_min_games ... free_max_games live games (defaults 17 ... 800; at most 1024): every
+ *                                 game keeps its own iteration counter, a launch of 512 / 1024 rows (free_rows1024_from, default 200 games; 128 rows of the cluster family below 41 games) carries the
  *                                 leaves the games wait for and the nodes their virtual descents predict; no kernel of it waits for a co-resident
  *                                 workgroup.  Default 1; same results.  free_rollout_steps / free_cand_max (12 / 6): virtual descents / candidates per
  *                                 game and round; free_iter_cap (4): iterations a game runs per launch at most; free_cand_x4 (8): candidates per game and round = 1 + this / 4 x the spare rows per game; free_ring (128): launches whose rows are kept; free_lds_nodes: cap of the tree nodes staged in LDS (tests)

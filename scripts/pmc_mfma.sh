@@ -15,7 +15,7 @@ for G in 1024 32; do
   SUF=""; [ $G = 32 ] && SUF="_32boards"
   CMD="python3 bench.py --no-cpu-baseline --pipeline 0 --hbm-only-steps 0 --max-steps 1 --games $G"
   # (32 boards: DIEE_SPEC_EVAL=0 = the launch-per-iteration search, every launch of k_tower_cl<1,8> at exactly 32 boards)
-  export DIEE_SPEC_EVAL=1; [ $G = 32 ] && { export DIEE_SPEC_EVAL=0; CMD="DIEE_SPEC_EVAL=0 $CMD"; }
+  export DIEE_SPEC_EVAL=1 DIEE_FREE_EVAL=1; [ $G = 32 ] && { export DIEE_SPEC_EVAL=0 DIEE_FREE_EVAL=0; CMD="DIEE_SPEC_EVAL=0 DIEE_FREE_EVAL=0 $CMD"; }
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$W/a_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --pipeline 0 --hbm-only-steps 0 --max-steps 1 --games $G > /dev/null 2>> "$OUT/${TAG}_pmc_err.log"
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 -d "$W/b_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --pipeline 0 --hbm-only-steps 0 --max-steps 1 --games $G > /dev/null 2>> "$OUT/${TAG}_pmc_err.log"
   A=$(find "$W/a_$G" -name '*counter_collection.csv' | head -1)

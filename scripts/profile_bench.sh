@@ -18,9 +18,9 @@ cp "$(find "$W/headline" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_head
 for G in 1024 32; do
   for C in FETCH_SIZE WRITE_SIZE; do
     # (32 boards: the launch-per-iteration search, so that k_tower_cl<1,8> runs at exactly 32 boards in every launch -- with the
-    # tail path on, a 32-game search sends 128-row launches of k_tower_cl<4,8> whose row count varies)
+    # free-running search / the tail on, a 32-game search sends 128-row launches of k_tower_cl<4,8> whose row count varies)
     SPEC=1; [ $G = 32 ] && SPEC=0
-    DIEE_SPEC_EVAL=$SPEC rocprofv3 --kernel-trace --pmc $C -d "$W/pmc_${C}_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --hbm-only-steps 0 --games $G > /dev/null 2>> "$OUT/${TAG}_err.log"
+    DIEE_SPEC_EVAL=$SPEC DIEE_FREE_EVAL=$SPEC rocprofv3 --kernel-trace --pmc $C -d "$W/pmc_${C}_$G" --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --max-steps 1 --pipeline 0 --hbm-only-steps 0 --games $G > /dev/null 2>> "$OUT/${TAG}_err.log"
   done
   F=$(find "$W/pmc_FETCH_SIZE_$G" -name '*counter_collection.csv' | head -1)
   Wr=$(find "$W/pmc_WRITE_SIZE_$G" -name '*counter_collection.csv' | head -1)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 SEED = 0xD1EE0001
 KEYS = ("nn_evals", "expansions", "children", "terminal_hits", "depth_sum", "selections", "max_children")
-DEFAULTS = dict(free_eval=1, free_min_games=129, free_max_games=768, free_rows1024_from=200, free_rollout_steps=24, free_cand_max=12,
+DEFAULTS = dict(free_eval=1, free_min_games=129, free_max_games=800, free_rows1024_from=200, free_rollout_steps=24, free_cand_max=12,
                 free_ring=128, free_lds_nodes=3072, free_iter_cap=4)
 
 

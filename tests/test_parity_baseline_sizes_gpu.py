@@ -109,7 +109,7 @@ def test_compacted_evaluation_bit_exact_vs_oracle(eng, oracle, n, iters, quirks)
     states = mixed_roots(oracle, n)
     roots, probs, os_, r = run_both(eng, oracle, states, iters, quirks, step=3)
     assert_search_equal(roots, probs, os_, r)
-    if n <= 768:
+    if n <= 800:
         assert r["stats"]["tail_iterations"] == iters            # the free-running search ran
         eng.set_option("free_eval", 0)
         try:
