@@ -11,6 +11,9 @@ in host memory when it ends (`value_hbm_only`: the same batches with the records
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3}] [--games G] [--iterations I]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` typed alone (N > 1, no RANK in the environment) starts its own N ranks -- a child torch.distributed.run on
+127.0.0.1 and a free port, before anything that could touch a GPU is imported -- and passes rank 0's line through (launch_ranks).
+
 Multi-GPU: games are independent, so ranks are independent data-parallel workers (weak scaling,
 no data-path collective); torch.distributed (RCCL) only provides the barrier and the max/sum of
 the per-rank timings and counters.
@@ -27,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_EVAL = 1_082_450_064
-PROFILE_SET = "r05r"          # ONE prefix under profiles/ for every figure this line reads from committed counter passes (scripts/profile_bench.sh + scripts/pmc_mfma.sh TAG)
+PROFILE_SET = "r06z"          # ONE prefix under profiles/ for every figure this line reads from committed counter passes (scripts/profile_bench.sh + scripts/pmc_mfma.sh TAG)
 MFMA_BUSY_FILE, MFMA_BUSY_FILE_32 = f"{PROFILE_SET}_mfma_busy.json", f"{PROFILE_SET}_mfma_busy_32boards.json"     # (the 32-board pass with DIEE_SPEC_EVAL=0)
 TRAFFIC_FILE, TRAFFIC_FILE_32 = f"{PROFILE_SET}_pmc_traffic.json", f"{PROFILE_SET}_pmc_traffic_32boards.json"
 
