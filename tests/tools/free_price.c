@@ -27,6 +27,9 @@ typedef struct {
     int lockstep;        /* 1: today's k_tail (all games iterate together or not at all) */
     int root_children;   /* 1: the root launch's free rows carry the roots' children (they exist before the evaluation: rules + dice) */
     int share_cap;       /* 0: free rows by rank over all games; > 0: at most this many speculative rows per game and launch */
+    int preexpand;       /* 1: PRICING of round-5 review item 5 (path-keyed child dice): a node's children are created -- states from dice keyed by the node's
+                            PATH, priors from its evaluation -- as soon as its evaluation arrives, invisible to the real search until it expands the node
+                            (then a commit), visible to the virtual descents: they run on into evaluated nodes and name GRANDCHILDREN as candidates */
     int prio;            /* grant order of the free rows: 0 rank by rank, games in slot order; 1 rank by rank, the games furthest behind first;
                             2 the games furthest behind get ALL their wishes first */
 } fp_cfg;
@@ -55,6 +58,7 @@ typedef struct {
     int* wish; int n_wish, wish_children0, wish_nchildren;   /* wish[i] >= 0: node; wish[i] = -1 - j: child j of the demanded leaf */
     or_state* child_state;                                    /* [child_rows] states of the children created ahead */
     float* vvis; float* vval; int vcap;
+    int* sh_first; int* sh_k; int sh_cap;                     /* preexpand: children created ahead of a node's expansion (first, count; 0: none) */
 } fp_game;
 
 static void ev_grow(fp_game* G) {
@@ -63,7 +67,23 @@ static void ev_grow(fp_game* G) {
     while (nc < G->st.n) nc *= 2;
     G->ev = realloc(G->ev, sizeof(fp_eval_t) * (size_t)nc);
     memset(G->ev + G->ev_cap, 0, sizeof(fp_eval_t) * (size_t)(nc - G->ev_cap));
+    G->sh_first = realloc(G->sh_first, sizeof(int) * (size_t)nc); G->sh_k = realloc(G->sh_k, sizeof(int) * (size_t)nc);
+    memset(G->sh_first + G->ev_cap, 0, sizeof(int) * (size_t)(nc - G->ev_cap)); memset(G->sh_k + G->ev_cap, 0, sizeof(int) * (size_t)(nc - G->ev_cap));
     G->ev_cap = nc;
+}
+
+/* dice key of a node's children when they are keyed by the node's path from the root (round-5 review item 5) instead of the iteration that expands it */
+static uint32_t path_key(const fp_game* G, int idx) {
+    int ord[256], d = 0;
+    for (int i = idx; G->st.nodes[i].parent >= 0 && d < 256; i = G->st.nodes[i].parent) {
+        const int p = G->st.nodes[i].parent;
+        int fc = G->st.nodes[p].n_children > 0 ? G->st.nodes[p].first_child : G->sh_first[p];
+        ord[d++] = i - fc;
+    }
+    uint32_t h = 0;
+    for (int k = d - 1; k >= 0; --k) { h = (h ^ ((uint32_t)ord[k] + 0x9E3779B9u)) * 0x85EBCA6Bu; h ^= h >> 13; }
+    if (h >= 0xFFFFFFF0u) h -= 0x10u;
+    return idx == 0 ? 0u : (h | 1u);
 }
 
 /* the evaluation of one state -> what an expansion needs of it */
@@ -76,11 +96,17 @@ static void ev_fill(const or_game* g, fp_eval_t* e, const or_state* s, const flo
 
 static int is_terminal(const or_game* g, const or_state* s, int* winner) { return g->check_winner(s, winner); }
 
-/* alpha_expand_tensor with the priors of a stored evaluation (expand_node's arithmetic: sequential sum in play order) */
+/* alpha_expand_tensor with the priors of a stored evaluation (expand_node's arithmetic: sequential sum in play order).  shadow = 1: the children are
+ * created but the node stays a leaf for the real search (preexpand); a later real expansion only commits them */
 static void fp_expand(const or_game* g, fp_game* G, int idx, const fp_eval_t* e, uint64_t seed, uint32_t eit, const float* noise, float eps,
-                      or_play* plays, long* rows_used) {
+                      or_play* plays, int shadow) {
     or_node* nd = &G->st.nodes[idx];
     if (nd->drained) return;
+    if (!shadow && G->sh_k[idx] > 0) {                /* commit what was created ahead */
+        nd->first_child = G->sh_first[idx]; nd->n_children = G->sh_k[idx]; nd->drained = 1;
+        return;
+    }
+    if (shadow && G->sh_k[idx] != 0) return;
     or_state s = nd->state;
     int k = g->valid_moves(&s, plays, OR_MAX_PLAYS);
     float* p = malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
@@ -98,16 +124,16 @@ static void fp_expand(const or_game* g, fp_game* G, int idx, const fp_eval_t* e,
         g->apply_move(&ns, &plays[j], d0, d1);
         store_add(&G->st, &ns, idx, (int)g->encode(&s, &plays[j]), p[j] / sum);
     }
-    nd = &G->st.nodes[idx];
-    nd->first_child = k ? first : -1; nd->n_children = k; nd->drained = 1;
     free(p);
     ev_grow(G);
+    nd = &G->st.nodes[idx];
+    if (shadow) { G->sh_first[idx] = first; G->sh_k[idx] = k > 0 ? k : -1; return; }      /* (-1: nothing to create; the real expansion drains the node) */
+    nd->first_child = k ? first : -1; nd->n_children = k; nd->drained = 1;
     if (G->ahead_leaf == idx) {                       /* the children evaluated ahead of this expansion take their rows */
         for (int j = 0; j < G->ahead_n && j < k; ++j) G->ev[first + j] = G->ahead[j];
         for (int j = k; j < G->ahead_n; ++j) free(G->ahead[j].pr);
         G->ahead_leaf = -1; G->ahead_n = 0;
     }
-    (void)rows_used;
 }
 
 /* selection for the game's next iteration; a finished game is backpropagated at once (alpha_mcts.rs:157-163) */
@@ -129,7 +155,7 @@ static void fp_iterate(const or_game* g, fp_game* G, const fp_cfg* cfg, uint64_t
         fp_eval_t* e = &G->ev[G->leaf];
         if (!e->used) { e->used = 1; out->rows_used++; }
         const float v = e->value;
-        fp_expand(g, G, G->leaf, e, seed, (uint32_t)G->it + 1u, NULL, 0.0f, plays, &out->rows_used);
+        fp_expand(g, G, G->leaf, e, seed, cfg->preexpand ? path_key(G, G->leaf) : (uint32_t)G->it + 1u, NULL, 0.0f, plays, 0);
         or_backpropagate(&G->st, G->leaf, v);
     }
     G->it++;
@@ -154,17 +180,19 @@ static void fp_plan(const or_game* g, fp_game* G, const fp_cfg* cfg, uint64_t se
             int idx = 0;
             for (;;) {
                 const or_node* nd = &G->st.nodes[idx];
-                if (nd->n_children == 0) break;
+                int nk = nd->n_children, nf = nd->first_child;
+                if (nk == 0 && cfg->preexpand && G->sh_k[idx] > 0) { nk = G->sh_k[idx]; nf = G->sh_first[idx]; }      /* created ahead: the descent goes on */
+                if (nk == 0) break;
                 const float sq = sqrtf(G->vvis[idx]);
                 int best = -1; float bs = 0.0f;
-                for (int j = 0; j < nd->n_children; ++j) {
-                    const int ch = nd->first_child + j;
+                for (int j = 0; j < nk; ++j) {
+                    const int ch = nf + j;
                     const float vis = G->vvis[ch], val = G->vval[ch];
                     const float q = vis == 0.0f ? 0.0f : val / vis;
                     const float s = q + (cfg->c * (sq / (vis + 1.0f))) * G->st.nodes[ch].policy;
                     if (s == s && (best < 0 || !(bs > s))) { best = ch; bs = s; }
                 }
-                idx = best >= 0 ? best : nd->first_child + nd->n_children - 1;
+                idx = best >= 0 ? best : nf + nk - 1;
             }
             float x = 0.0f;
             int w, fresh = 0;
@@ -239,7 +267,7 @@ int fp_run(const or_state* roots, int m, const fp_cfg* cfg, uint64_t seed, uint3
         fp_game* G = &Gs[i];
         ev_fill(g, &G->ev[0], &roots[i], pol + (size_t)i * A, val[i], plays);
         G->ev[0].used = 1; out->rows_used++;
-        fp_expand(g, G, 0, &G->ev[0], seed, 0u, noise, cfg->dir_eps, plays, &out->rows_used);
+        fp_expand(g, G, 0, &G->ev[0], seed, 0u, noise, cfg->dir_eps, plays, 0);
     }
     if (cfg->root_children && R > m) {
         /* free rows of the root launch: the roots' children in turn (child j of every game, then j + 1 ...), as far as the rows go.
@@ -354,7 +382,12 @@ int fp_run(const or_state* roots, int m, const fp_cfg* cfg, uint64_t seed, uint3
         }
         for (int r = 0; r < nb; ++r) {
             fp_game* G = &Gs[bgame[r]];
-            if (bwish[r] >= 0) { if (!G->ev[bwish[r]].have) ev_fill(g, &G->ev[bwish[r]], &bstate[r], pol + (size_t)r * A, val[r], plays); }
+            if (bwish[r] >= 0) {
+                if (!G->ev[bwish[r]].have) ev_fill(g, &G->ev[bwish[r]], &bstate[r], pol + (size_t)r * A, val[r], plays);
+                int w;
+                if (cfg->preexpand && !G->st.nodes[bwish[r]].drained && !is_terminal(g, &G->st.nodes[bwish[r]].state, &w))
+                    fp_expand(g, G, bwish[r], &G->ev[bwish[r]], seed, path_key(G, bwish[r]), NULL, 0.0f, plays, 1);
+            }
             else {
                 const int j = -1 - bwish[r];
                 if (G->ahead_leaf != G->leaf) { G->ahead_leaf = G->leaf; G->ahead_n = 0; memset(G->ahead, 0, sizeof G->ahead); }
@@ -369,6 +402,7 @@ int fp_run(const or_state* roots, int m, const fp_cfg* cfg, uint64_t seed, uint3
         out->rounds_of_game_sum += G->rounds; if (G->rounds > out->rounds_of_game_max) out->rounds_of_game_max = G->rounds;
         for (int k = 0; k < G->ev_cap; ++k) free(G->ev[k].pr);
         for (int j = 0; j < G->ahead_n; ++j) free(G->ahead[j].pr);
+        free(G->sh_first); free(G->sh_k);
         free(G->ev); free(G->wish); free(G->child_state); free(G->vvis); free(G->vval); or_store_free(&G->st);
     }
     free(adv); free(order_); free(Gs); free(plays); free(bstate); free(bgame); free(bwish); free(pol); free(val); free(noise);

@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 class Cfg(C.Structure):
     _fields_ = [("iterations", C.c_int), ("c", C.c_float), ("dir_alpha", C.c_float), ("dir_eps", C.c_float), ("rows", C.c_int),
                 ("child_rows", C.c_int), ("cand_max", C.c_int), ("rollouts", C.c_int), ("order", C.c_int), ("lockstep", C.c_int),
-                ("root_children", C.c_int), ("share_cap", C.c_int), ("prio", C.c_int)]
+                ("root_children", C.c_int), ("share_cap", C.c_int), ("preexpand", C.c_int), ("prio", C.c_int)]
 
 
 class Out(C.Structure):
@@ -119,7 +119,7 @@ def main():
     def run(states, rounds, **kw):
         m = len(states)
         d = dict(iterations=args.iterations, c=2.0, dir_alpha=0.3, dir_eps=0.25, rows=1024, child_rows=16, cand_max=8, rollouts=24, order=1,
-                 lockstep=0, root_children=0, share_cap=0, prio=0)
+                 lockstep=0, root_children=0, share_cap=0, preexpand=0, prio=0)
         d.update(kw)
         cfg = Cfg(**d); out = Out()
         gids = np.arange(m, dtype=np.uint32)
@@ -151,7 +151,8 @@ def main():
             variants = [("lockstep (today's k_tail policy)", dict(lockstep=1, cand_max=24)),
                         ("free, demanded only", dict(child_rows=0, cand_max=0)),
                         ("free, 8 cands then children (order 0)", dict(order=0)),
-                        ("free, first cand, children, cands (order 1)", dict(order=1))]
+                        ("free, first cand, children, cands (order 1)", dict(order=1)),
+                        ("free, 8 cands, no children, PRE-EXPANSION (path-keyed dice)", dict(order=0, child_rows=0, preexpand=1))]
             if not args.quick:
                 variants += [("free, 8 cands, no children", dict(order=0, child_rows=0)),
                              ("free, 16 cands then children", dict(order=0, cand_max=16)),
@@ -160,7 +161,9 @@ def main():
                              ("free, 8 cands then children, games behind take all (prio 2)", dict(order=0, prio=2)),
                              ("free, 16 cands then children, prio 1", dict(order=0, cand_max=16, prio=1)),
                              ("free, 16 cands then children, prio 1 + root children", dict(order=0, cand_max=16, prio=1, root_children=1)),
-                             ("free, order 2 (children first when the descent deepens)", dict(order=2))]
+                             ("free, order 2 (children first when the descent deepens)", dict(order=2)),
+                             ("free, 8 cands, no children, PRE-EXPANSION (path-keyed dice)", dict(order=0, child_rows=0, preexpand=1)),
+                             ("free, 16 cands, no children, PRE-EXPANSION", dict(order=0, child_rows=0, preexpand=1, cand_max=16, rollouts=48))]
             for name, kw in variants:
                 if kw.get("lockstep") and m > 512:
                     continue
