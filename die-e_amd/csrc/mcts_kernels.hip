@@ -1153,6 +1153,13 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     if (F.state[0] != 0u) return;                               // every game was done when the previous round was packed
     uint32_t it = F.prog[slot];
     if (it >= F.iterations) { if (lane == 0) F.wish_n[slot] = it << 8; return; }
+    // The games still searching when the last round was packed.  A search ends when its LAST game is done, and the last few games have the
+    // launches to themselves (traced: 11 of 37 rounds at 300 games carried the rows of one to four games, profiles/r06v_*): with few games
+    // left a game runs as many iterations as its rows allow and lists as many candidates as the launch has room for
+    const uint32_t active0 = A.q == 0 ? n : F.state[4];
+    const uint32_t active = active0 ? active0 : 1u;
+    const bool few = active * 8u <= n || active <= 8u;
+    const uint32_t iter_cap = few ? 64u * F.iter_cap : F.iter_cap;
 #ifdef DIEE_TAIL_STAMPS
     unsigned long long fr_prev_ = __builtin_readcyclecounter();
     const unsigned long long fr_t0_ = fr_prev_;
@@ -1265,7 +1272,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     for (;; ++ran) {
         have = lterm || at_hand(cr);
         if (!have) break;
-        if (ran >= F.iter_cap) { stalled = true; break; }       // (enough for this launch: the other games' workgroups are done long since)
+        if (ran >= iter_cap) { stalled = true; break; }       // (enough for this launch: the other games' workgroups are done long since)
         // ---- the flag words of this iteration, where the game needs them ----
         uint32_t* iflag = S.iter_flags + 2 * ((size_t)seg * G.iter_cap + it);
         const bool need_cnt = quirks && slot == seg_first && it < fsel;
@@ -1472,16 +1479,22 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
         if (dem) { if (lane == 0) wl[0] = leaf; nw = 1; }
         // (the launch lasts as long as its busiest game: one that ran its full share of iterations -- it is ahead of the others and the rows it was
         // granted served it well -- looks for fewer candidates: every iteration it ran takes two virtual descents off its budget)
-        const uint32_t want0 = F.cand_max < kFreeWish - 1u ? F.cand_max : kFreeWish - 1u;
-        const uint32_t want = want0 > ran / 2u + 1u ? want0 - ran / 2u : (want0 ? 1u : 0u);
+        uint32_t want0 = F.cand_max < kFreeWish - 1u ? F.cand_max : kFreeWish - 1u;
+        uint32_t steps_max = F.rollout_steps;
+        if (few && want0) {                                     // the spare rows per game STILL SEARCHING, not per live game
+            const uint32_t room = (F.rows > active ? F.rows - active : 0u) / active;
+            want0 = room + 1u < kFreeWish - 1u ? (room + 1u > want0 ? room + 1u : want0) : kFreeWish - 1u;
+            steps_max = 2u * F.rollout_steps + 8u;
+        }
+        const uint32_t want = few ? want0 : (want0 > ran / 2u + 1u ? want0 - ran / 2u : (want0 ? 1u : 0u));
         uint32_t ncand = 0;
-        if (want > 0 && F.rollout_steps > 0) {
+        if (want > 0 && steps_max > 0) {
             const uint32_t nu = used < ln ? used : ln;
             for (uint32_t i = lane; i < nu; i += 64) { vvis[i] = lvis[i]; vval[i] = lval[i]; }
             __syncthreads();
             const uint32_t demanded = dem ? leaf : kNone;
             uint32_t fruitless = 0;
-            for (uint32_t step = 0; step < F.rollout_steps && ncand < want && fruitless < 8; ++step) {
+            for (uint32_t step = 0; step < steps_max && ncand < want && fruitless < 8; ++step) {
                 uint32_t node = 0, depth = 0, mine = lane == 0 ? 0u : kNone, mt = 0;
                 for (;;) {
                     mt = X.hdr(node);
@@ -1527,43 +1540,47 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
 #endif
 }
 
-// The rows of launch q: every demanded leaf, then the other wishes rank by rank (every game's first candidate, then every game's second ...)
-// until the launch is full; a game's rows are contiguous (k_free takes them in by grant_off / grant_cnt).  One workgroup, one thread per game,
-// the games in an order that turns with the launch (the rank that does not fit whole goes to the games that come first).
+// The rows of launch q: every demanded leaf, then the other wishes rank by rank (every game's first candidate, then every game's second ...; the
+// games behind the leader a few ranks earlier) until the launch is full; a game's rows are contiguous (k_free takes them in by grant_off /
+// grant_cnt).  One workgroup, one thread per game, the games in an order that turns with the launch (the rank that does not fit whole goes to
+// the games that come first).
 __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t node_cap, uint32_t q, const BgState* __restrict__ arena) {
-    __shared__ uint32_t hist[kFreeWish + 1];
+    constexpr uint32_t kBoost = 4, kLagStep = 4;               // a game kLagStep iterations behind the leader is served one rank earlier, up to kBoost ranks
+    __shared__ uint32_t hist[kFreeWish + kBoost + 2];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_full, s_rem, s_dem, s_undone;
+    __shared__ uint32_t s_full, s_rem, s_dem, s_undone, s_maxprog;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (F.state[0] != 0u) return;                               // the search was complete a round ago: n_rows[q] stays 0
-    if (tid <= (int)kFreeWish) hist[tid] = 0;
-    if (tid == 0) { s_dem = 0; s_undone = 0; }
+    if (tid < (int)(kFreeWish + kBoost + 2)) hist[tid] = 0;
+    if (tid == 0) { s_dem = 0; s_undone = 0; s_maxprog = 0; }
     __syncthreads();
     const uint32_t rot = (q * 131u) % n;
     const uint32_t g = (uint32_t)tid < n ? ((uint32_t)tid + rot) % n : 0u;
     const uint32_t w = (uint32_t)tid < n ? F.wish_n[g] : ((F.iterations) << 8);
-    const uint32_t cnt = w & 0xffu, dem = w >> 31, spec = cnt - dem;
-    const bool undone = ((w >> 8) & 0x7fffffu) < F.iterations;
-    if ((uint32_t)tid < n) { atomicAdd(&hist[spec], 1u); if (dem) atomicAdd(&s_dem, 1u); if (undone) atomicOr(&s_undone, 1u); }
+    const uint32_t cnt = w & 0xffu, dem = w >> 31, spec = cnt - dem, prog = (w >> 8) & 0x7fffffu;
+    const bool undone = prog < F.iterations;
+    if ((uint32_t)tid < n && undone) { atomicMax(&s_maxprog, prog); atomicAdd(&s_undone, 1u); if (dem) atomicAdd(&s_dem, 1u); }
+    __syncthreads();
+    // A search ends when its LAST game is done: the games behind are served first.  Wish number r of a game that is `lag` iterations behind
+    // the leader competes as rank r + kBoost - min(kBoost, lag / kLagStep); every rank that fits whole is granted, the next one as far as the rows go.
+    const uint32_t lag = undone ? s_maxprog - prog : 0u;
+    const uint32_t shift = kBoost - (lag / kLagStep < kBoost ? lag / kLagStep : kBoost);      // 0 (furthest behind) ... kBoost (the leaders)
+    if ((uint32_t)tid < n) for (uint32_t r = 1; r <= spec; ++r) atomicAdd(&hist[r + shift], 1u);
     __syncthreads();
     if (tid == 0) {
         const uint32_t room = F.rows > s_dem ? F.rows - s_dem : 0u;
-        uint32_t full = 0, used_rows = 0, at_least = 0;
-        // games that wish for at least r rows, r = kFreeWish ... 1, turned into "ranks that fit whole"
-        uint32_t ge[kFreeWish + 2];
-        ge[kFreeWish + 1] = 0;
-        for (int r = (int)kFreeWish; r >= 0; --r) ge[r] = ge[r + 1] + hist[r];
-        for (uint32_t r = 1; r <= kFreeWish; ++r) {
-            at_least = ge[r];
-            if (at_least == 0 || used_rows + at_least > room) break;
-            used_rows += at_least; full = r;
+        uint32_t full = 0, used_rows = 0;
+        for (uint32_t k = 1; k <= kFreeWish + kBoost; ++k) {
+            if (used_rows + hist[k] > room) break;
+            used_rows += hist[k]; full = k;
         }
         s_full = full; s_rem = room - used_rows;
     }
     __syncthreads();
     const uint32_t full = s_full, rem = s_rem;
-    // the next rank, as far as the rows go: the first `rem` games (in this launch's order) that wish for more than `full`
-    const int more = ((uint32_t)tid < n && spec > full) ? 1 : 0;
+    // wishes of rank <= full: r + shift <= full, i.e. r <= full - shift; the next rank (full + 1) as far as the rows go, in this launch's order of the games
+    const uint32_t whole = full > shift ? (full - shift < spec ? full - shift : spec) : 0u;
+    const int more = ((uint32_t)tid < n && spec > whole && whole + 1u + shift == full + 1u) ? 1 : 0;
     int inc = wave_inclusive_scan_i32(more);
     if (lane == 63) wsum[wave] = (uint32_t)inc;
     __syncthreads();
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
     for (int v = 0; v < wave; ++v) before += wsum[v];
     const uint32_t my_rank = before + (uint32_t)(inc - more);
     __syncthreads();
-    const uint32_t grant = (uint32_t)tid < n ? dem + (spec < full ? spec : full) + ((more && my_rank < rem) ? 1u : 0u) : 0u;
+    const uint32_t grant = (uint32_t)tid < n ? dem + whole + ((more && my_rank < rem) ? 1u : 0u) : 0u;
     inc = wave_inclusive_scan_i32((int)grant);
     if (lane == 63) wsum[wave] = (uint32_t)inc;
     __syncthreads();
@@ -1594,7 +1611,7 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
         if (total > F.rows) total = F.rows;
         F.n_rows[q] = total; F.n_dem[q] = s_dem < total ? s_dem : total;
         const uint32_t all_done = s_undone ? 0u : 1u;
-        F.state[0] = all_done;
+        F.state[0] = all_done; F.state[4] = s_undone;
         if (total) { F.state[1] += 1u; F.state[2] += total - s_dem; }
         F.host[0] = all_done; F.host[1] = q;
         __threadfence_system();

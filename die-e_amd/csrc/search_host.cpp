@@ -47,7 +47,7 @@ struct SearchBufs {
     uint32_t tl_prev_need = 0;                                 // tower launches the previous move-step's search needed (sizes the first chunk)
     uint64_t tl_iterations = 0, tl_launched = 0, tl_with_rows = 0, tl_spec_rows = 0, tl_syncs = 0;      // this call's totals
     // the free-running search (search_types.h, Free)
-    DevBuf<uint32_t> fr_crow, fr_rows_idx, fr_words, fr_slots, fr_wish;      // fr_words = n_rows[launches] ++ state[4]; fr_slots = grant_off ++ grant_cnt ++ wish_n ++ prog ++ first_sel, [slots] each
+    DevBuf<uint32_t> fr_crow, fr_rows_idx, fr_words, fr_slots, fr_wish;      // fr_words = n_rows[launches] ++ n_dem[launches] ++ state[8]; fr_slots = grant_off ++ grant_cnt ++ wish_n ++ prog ++ first_sel, [slots] each
     DevBuf<float> fr_cval, fr_logits, fr_hv;
     DevBuf<BgState> fr_rows_state;                              // dense states of the launches of at most 128 rows (cluster family)
     uint32_t* fr_host = nullptr;                                // pinned, [2]
@@ -389,7 +389,7 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
         B.fr_rows_state.ensure((size_t)W * std::min<uint32_t>(R, kTailRowsMax));
         B.fr_ring = W; B.fr_rows = R;
     }
-    if (launches > B.fr_launches) { B.fr_words.ensure(2 * (size_t)launches + 4); B.fr_launches = launches; }
+    if (launches > B.fr_launches) { B.fr_words.ensure(2 * (size_t)launches + 8); B.fr_launches = launches; }
     if (!B.fr_host) { HIPCHK(hipHostMalloc((void**)&B.fr_host, sizeof(uint32_t) * 2)); memset(B.fr_host, 0, sizeof(uint32_t) * 2); }
     if (!B.cus) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, e.device)); B.cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     uint32_t* sl = B.fr_slots.p;
@@ -414,7 +414,7 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     // crow of the slots in use (the trees are rebuilt every move-step), the row counts and state words, the per-slot progress (first_sel is
     // written by round 0)
     HIPCHK(hipMemsetAsync(F.crow, 0, sizeof(uint32_t) * (size_t)n * T.node_cap, st));
-    HIPCHK(hipMemsetAsync(B.fr_words.p, 0, sizeof(uint32_t) * (2 * (size_t)B.fr_launches + 4), st));
+    HIPCHK(hipMemsetAsync(B.fr_words.p, 0, sizeof(uint32_t) * (2 * (size_t)B.fr_launches + 8), st));
     HIPCHK(hipMemsetAsync(B.fr_slots.p, 0, sizeof(uint32_t) * (size_t)5 * B.fr_slot_cap, st));
     B.fr_host[0] = 0; B.fr_host[1] = 0xFFFFFFFFu;
     launch_free(st, T, S, G, n, P, cfg.c, F, 0);
@@ -445,6 +445,13 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     if (e.opt.trace_steps)
         fprintf(stderr, "[diee] free-running: %u games, %u iterations on %u launches with rows of <= %u (%u rounds sent), %u speculative rows, %u nodes in LDS\n",
                 n, cfg.iterations, words[1], F.rows, sent, words[2], F.lds_nodes);
+    if (e.opt.trace_steps >= 2) {                                      // development: the rows of every round (where the stragglers' rounds begin)
+        std::vector<uint32_t> nr((size_t)sent + 1), nd((size_t)sent + 1);
+        e.d2h(nr.data(), F.n_rows, nr.size()); e.d2h(nd.data(), F.n_dem, nd.size()); e.sync();
+        fprintf(stderr, "[diee] free-running rounds (rows/demanded):");
+        for (size_t i = 0; i < nr.size(); ++i) fprintf(stderr, " %u/%u", nr[i], nd[i]);
+        fprintf(stderr, "\n");
+    }
     B.fr_prev_need = words[1];
     B.tl_iterations += cfg.iterations; B.tl_launched += sent; B.tl_with_rows += words[1]; B.tl_spec_rows += words[2];
 }

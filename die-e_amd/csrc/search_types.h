@@ -184,7 +184,8 @@ struct Free {
     uint32_t* wish_n;       // [slots] count | 0x80000000 when wish[0] is the demanded leaf | progress << 8 (the packer may favour games behind)
     uint32_t* prog;         // [slots] the iteration whose selection the game has published = its own iteration counter
     uint32_t* first_sel;    // [slots] iteration of the game's first real selection (0xFFFFFFFF: none yet): Q14's count matters only before it
-    uint32_t* state;        // [0] all games done, [1] launches that carried rows, [2] rows evaluated on speculation, [3] iterations run
+    uint32_t* state;        // [0] all games done, [1] launches that carried rows, [2] rows evaluated on speculation, [4] games not done when the last round was
+                            // packed (k_free sizes its budgets by them: the last games of a search have the launches to themselves)
     uint32_t* host;         // pinned: [0] done, [1] last k_free_pack that finished
     uint32_t launches;      // iterations + 2
     uint32_t iterations;
