@@ -37,7 +37,8 @@ const OptEntry kOptions[] = {
     {"free_eval", &Options::free_eval, nullptr, nullptr}, {"free_min_games", nullptr, &Options::free_min_games, nullptr},
     {"free_max_games", nullptr, &Options::free_max_games, nullptr}, {"free_rows1024_from", nullptr, &Options::free_rows1024_from, nullptr},
     {"free_rollout_steps", nullptr, &Options::free_rollout_steps, nullptr}, {"free_cand_max", nullptr, &Options::free_cand_max, nullptr},
-    {"free_ring", nullptr, &Options::free_ring, nullptr}, {"free_iter_cap", nullptr, &Options::free_iter_cap, nullptr}, {"free_cand_x4", nullptr, &Options::free_cand_x4, nullptr}, {"free_lds_nodes", nullptr, &Options::free_lds_nodes, nullptr},
+    {"free_ring", nullptr, &Options::free_ring, nullptr}, {"free_iter_cap", nullptr, &Options::free_iter_cap, nullptr}, {"free_cand_x4", nullptr, &Options::free_cand_x4, nullptr},
+    {"free_lag_boost", nullptr, &Options::free_lag_boost, nullptr}, {"free_lag_step", nullptr, &Options::free_lag_step, nullptr}, {"free_lds_nodes", nullptr, &Options::free_lds_nodes, nullptr},
     {"path_cap", nullptr, &Options::path_cap, nullptr}, {"nodes_per_expansion", nullptr, &Options::nodes_per_expansion, nullptr},
     {"deliver_stage_rows", nullptr, &Options::deliver_stage_rows, nullptr}, {"deliver_rows_per_game", nullptr, &Options::deliver_rows_per_game, nullptr},
     {"trace_steps", &Options::trace_steps, nullptr, nullptr}, {"trace_dispatch", &Options::trace_dispatch, nullptr, nullptr},

@@ -74,6 +74,7 @@ struct Options {
     uint32_t free_rows1024_from = 200;      // live games from which a launch of it is one pass of the chip (1024 rows) instead of the pair tower's 512 (profiles/r06e_*)
     uint32_t free_rollout_steps = 24, free_cand_max = 12;    // virtual descents / candidates per game and round at most (the candidates follow the spare rows: free_view)
     uint32_t free_cand_x4 = 8;              // candidates per game and round = 1 + this / 4 x the spare rows per game (8: twice the rows a game can hope for)
+    uint32_t free_lag_boost = 4, free_lag_step = 4;          // the packer serves a game free_lag_step iterations behind the leader one rank earlier, up to free_lag_boost ranks (<= 16; 0: off)
     uint32_t free_iter_cap = 4;             // iterations a game runs in one of its launches at most
     uint32_t free_ring = 128;               // launches whose rows stay in its ring (a row that aged out is evaluated again: same bits)
     uint32_t free_lds_nodes = 3072;         // cap of the tree nodes k_free stages in LDS per game (tests lower it to reach the in-place path)

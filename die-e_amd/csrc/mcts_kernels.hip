@@ -1545,13 +1545,13 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
 // grant_cnt).  One workgroup, one thread per game, the games in an order that turns with the launch (the rank that does not fit whole goes to
 // the games that come first).
 __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t node_cap, uint32_t q, const BgState* __restrict__ arena) {
-    constexpr uint32_t kBoost = 4, kLagStep = 4;               // a game kLagStep iterations behind the leader is served one rank earlier, up to kBoost ranks
-    __shared__ uint32_t hist[kFreeWish + kBoost + 2];
+    const uint32_t kBoost = F.lag_boost < kFreeBoostMax ? F.lag_boost : kFreeBoostMax, kLagStep = F.lag_step ? F.lag_step : 1u;
+    __shared__ uint32_t hist[kFreeWish + kFreeBoostMax + 2];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_full, s_rem, s_dem, s_undone, s_maxprog;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (F.state[0] != 0u) return;                               // the search was complete a round ago: n_rows[q] stays 0
-    if (tid < (int)(kFreeWish + kBoost + 2)) hist[tid] = 0;
+    if (tid < (int)(kFreeWish + kFreeBoostMax + 2)) hist[tid] = 0;
     if (tid == 0) { s_dem = 0; s_undone = 0; s_maxprog = 0; }
     __syncthreads();
     const uint32_t rot = (q * 131u) % n;

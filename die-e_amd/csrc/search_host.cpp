@@ -399,6 +399,7 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
                 std::min<uint32_t>(free_lds_nodes_for(n, (uint32_t)B.cus), std::max<uint32_t>(e.opt.free_lds_nodes, 64u)), e.opt.free_rollout_steps,
                 // candidates per game and round: about twice the spare rows a game can hope for (what is not granted is found again next round), at most the option's
                 std::min<uint32_t>(e.opt.free_cand_max, 1u + (e.opt.free_cand_x4 * (rows - std::min(rows, n)) + 4u * n - 1u) / (4u * n)),
+                e.opt.free_lag_boost, e.opt.free_lag_step,
                 // iterations per game and launch: with few games and many spare rows a game often runs 6 ... 8 iterations on one launch's rows (profiles/r06h_*)
                 std::max<uint32_t>(n <= kTailRowsMax ? 2u * e.opt.free_iter_cap : e.opt.free_iter_cap, 1u)};
 }

@@ -169,6 +169,7 @@ struct Tail {
 // profiles/r06a_*.  Results are bit-identical to the lockstep search: the same operations on the same numbers in the same order per game.
 constexpr uint32_t kFreeWish = 24;        // wishes a game may list per round (demanded leaf included)
 constexpr uint32_t kFreeMaxSlots = 1024;  // k_free_pack: one thread per game
+constexpr uint32_t kFreeBoostMax = 16;
 struct Free {
     uint32_t* crow;         // [slots][node_cap] 1 + launch * rows + row of a node's evaluation (0: none); valid while launch + ring > the current launch
     float* cval;            // [slots][node_cap] its value (virtual descents only)
@@ -194,6 +195,7 @@ struct Free {
     uint32_t lds_nodes;     // nodes of a game's tree staged in LDS (by the workgroups that share a CU)
     uint32_t rollout_steps; // virtual descents per game and round at most
     uint32_t cand_max;      // candidates a game lists at most (< kFreeWish)
+    uint32_t lag_boost, lag_step;   // k_free_pack: a game lag_step iterations behind the leader is served one rank earlier, up to lag_boost ranks (<= kFreeBoostMax)
     uint32_t iter_cap;      // iterations a game runs in one launch at most: the launch lasts as long as its busiest game (a game whose leaves are
                             // finished games needs no rows and would run its whole search in the first one)
 };

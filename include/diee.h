@@ -189,7 +189,7 @@ diee_status diee_device_pci_bus_id(int device, char* out /*[cap], >= 16*/, size_
  *                                 game keeps its own iteration counter, a launch of 512 / 1024 rows (free_rows1024_from, default 200 games; 128 rows of the cluster family below 41 games) carries the
  *                                 leaves the games wait for and the nodes their virtual descents predict; no kernel of it waits for a co-resident
  *                                 workgroup.  Default 1; same results.  free_rollout_steps / free_cand_max (12 / 6): virtual descents / candidates per
- *                                 game and round; free_iter_cap (4): iterations a game runs per launch at most; free_cand_x4 (8): candidates per game and round = 1 + this / 4 x the spare rows per game; free_ring (128): launches whose rows are kept; free_lds_nodes: cap of the tree nodes staged in LDS (tests)
+ *                                 game and round; free_iter_cap (4): iterations a game runs per launch at most (lifted for the last games of a search); free_lag_boost / free_lag_step (4 / 4): the games behind the leader are granted their rows up to so many ranks earlier, one per so many iterations of lag; free_cand_x4 (8): candidates per game and round = 1 + this / 4 x the spare rows per game; free_ring (128): launches whose rows are kept; free_lds_nodes: cap of the tree nodes staged in LDS (tests)
  *   spec_ring_mb          MiB of HBM the ring of evaluated rows of such a search may take ((iterations + 1) launches x rows x 5.7 KB; default 8192):
  *                                 a search whose ring would be larger runs one launch per iteration instead
  *   pinned_pool_mb        MiB of page-locked output blocks the PROCESS keeps for reuse after diee_free_fragments (default 8192;
