@@ -164,3 +164,25 @@ def test_free_running_with_batches_side_by_side(eng, oracle):
         for key in KEYS:
             assert o["stats"][key] == r["stats"][key], key
     assert out[0]["stats"]["tail_iterations"] > 0
+
+
+def test_free_running_on_a_shared_gpu(oracle):
+    """`shared_gpu` = 1 takes every kernel that waits for a co-resident workgroup out of the dispatch (cluster tower, pair tower, k_tail); the
+    free-running search waits for nobody and stays on above 256 games: its rounds then run on the one-pass fused tower and, at 512 rows or fewer,
+    on the 2-board geometry instead of the pair tower -- one arithmetic, the same bits as the oracle's lockstep search"""
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    e.set_option("shared_gpu", 1)
+    try:
+        assert not any(k.startswith(("k_tower_cl", "k_tower16p")) for _, _, k in e.dispatch_bands(1024))
+        for n, iters in ((300, 24), (600, 16)):
+            states = roots_of(oracle, n, "mixed")
+            ocfg, gcfg = cfgs(oracle, iters)
+            gids = np.arange(n, dtype=np.uint32); rds = np.arange(n, dtype=np.uint32) % 3
+            roots, probs, ostats, _ = oracle.alpha_mcts_parallel(1, states, ocfg, gpu_eval(e, oracle), None, SEED, 8, gids, rds, 1)
+            r = e.alpha_mcts_parallel(states, gcfg, SEED, 8, gids, rds, ref_quirks=True)
+            check(r, roots, probs, ostats.as_dict(), f"shared_gpu, {n} games")
+            assert r["stats"]["tail_iterations"] == iters and r["stats"]["tail_launches"] < iters
+    finally:
+        e.close()
