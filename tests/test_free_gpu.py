@@ -83,16 +83,16 @@ def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, qu
     assert f["tail_launches"] <= d["tail_launches"]
     if pick != "late":                                   # the speculation pays: about 0.91 * n / rows launches per iteration (+ what the predictions miss)
         rows = 1024 if n >= 200 else 512
-        assert f["tail_spec_rows"] > 0 and f["tail_launches"] <= min(1.0, 1.45 * n / rows + 0.08) * iters, (f["tail_launches"], iters)
+        assert f["tail_spec_rows"] > 0 and f["tail_launches"] <= min(1.0, 1.6 * n / rows + 0.1) * iters, (f["tail_launches"], iters)
     print(f"[free] {n} games x {iters} iterations ({pick}, quirks {quirks}): {f['tail_launches']} launches with rows, {f['tail_spec_rows']} speculative rows "
           f"(demanded only: {d['tail_launches']})")
 
 
 @pytest.mark.parametrize("opts", [dict(free_lds_nodes=64), dict(free_ring=4), dict(free_rows1024_from=129), dict(free_rows1024_from=1024),
-                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000)])
+                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000), dict(free_lag_boost=0), dict(free_lag_boost=16, free_lag_step=1)])
 def test_free_running_options_change_nothing(eng, oracle, opts):
     """the tree's nodes beyond the LDS capacity are read in place, a ring of 4 launches makes evaluations age out (they are demanded again:
-    the same bits), 512- or 1024-row launches, many or few candidates: the same search"""
+    the same bits), 512- or 1024-row launches, many or few candidates, grants with and without a bonus for the games behind: the same search"""
     n, iters = 300, 48
     states = roots_of(oracle, n, "mixed")
     ocfg, gcfg = cfgs(oracle, iters)
