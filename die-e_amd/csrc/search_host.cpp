@@ -374,9 +374,13 @@ bool free_possible(Engine& e, uint32_t n, const diee_mcts_cfg& cfg) {
 
 Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
     const bool fused = free_fused(e, n);
-    const uint32_t launches = cfg.iterations + 2, rows = free_rows_for(e, n);
+    // rounds a search may take before the host gives up: about 0.91 * iterations * n / rows are needed; a game that advances one iteration per
+    // round needs iterations + 1; a round is lost where an evaluation aged out of the ring before its game's turn came (small rings, an
+    // iteration cap of 1) or where a game had to wait for another's flag words -- 4 x (iterations + games) covers what the option mixes of
+    // tests/tools/free_fuzz.py ever needed many times over (the words per round are 8 bytes)
+    const uint32_t launches = 4 * (cfg.iterations + n) + 66, rows = free_rows_for(e, n);
     // the ring holds the rows of the last `ring` launches: a whole search at iterations = 100, option free_ring launches beyond
-    const uint32_t ring = std::min<uint32_t>(launches, std::max<uint32_t>(e.opt.free_ring, 4u));
+    const uint32_t ring = std::min<uint32_t>(cfg.iterations + 2, std::max<uint32_t>(e.opt.free_ring, 4u));
     if (n > B.fr_slot_cap || B.node_cap > B.fr_node_cap) {
         const uint32_t sc = std::max(n, B.fr_slot_cap), nc = std::max(B.node_cap, B.fr_node_cap);
         B.fr_crow.ensure((size_t)sc * nc); B.fr_cval.ensure((size_t)sc * nc);
@@ -406,7 +410,8 @@ Free free_view(Engine& e, SearchBufs& B, const diee_mcts_cfg& cfg, uint32_t n) {
 
 // The iterations of one move-step's search for 257 ... 928 live games, behind the root expansion (k_expand has selected every game's leaf
 // for iteration 0): round 0 = { k_free, k_free_pack }, then rounds { tower launch q over the rows granted, k_free, k_free_pack }.  The game
-// furthest behind completes an iteration in every round, so `iterations` + 1 rounds always suffice -- and about 0.91 * n / rows of that do.
+// furthest behind completes an iteration in nearly every round (not where its evaluation aged out of the ring or a flag word of another game is
+// still missing), so about `iterations` + 1 rounds suffice at worst -- and about 0.91 * n / rows of that do; the bound is F.launches (free_view).
 // Rounds sent ahead of a search that is complete return at once, so they go out in chunks, the host looking at the done word in between.
 void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& G, const diee_mcts_cfg& cfg, const SearchParams& P) {
     SearchBufs& B = *e.search;
@@ -422,8 +427,8 @@ void free_run(Engine& e, uint32_t n, const Tree& T, const Slots& S, const Segs& 
     uint32_t q = 0, sent = 0;
     uint32_t chunk = B.fr_prev_need ? B.fr_prev_need + 2 : std::max<uint32_t>(8u, (uint32_t)((double)cfg.iterations * n / F.rows) + 4u);
     bool done = false;
-    while (!done && q <= cfg.iterations) {
-        const uint32_t end = std::min<uint32_t>(cfg.iterations + 1, q + std::max<uint32_t>(chunk, 1u));
+    while (!done && q + 1 < F.launches) {
+        const uint32_t end = std::min<uint32_t>(F.launches - 1, q + std::max<uint32_t>(chunk, 1u));
         for (; q < end; ++q, ++sent) {
             const size_t rb = (size_t)(q % F.ring) * F.rows;
             if (F.rows_state) {

@@ -188,7 +188,7 @@ struct Free {
     uint32_t* state;        // [0] all games done, [1] launches that carried rows, [2] rows evaluated on speculation, [4] games not done when the last round was
                             // packed (k_free sizes its budgets by them: the last games of a search have the launches to themselves)
     uint32_t* host;         // pinned: [0] done, [1] last k_free_pack that finished
-    uint32_t launches;      // iterations + 2
+    uint32_t launches;      // rounds the host sends at most: 4 x (iterations + games) + 66 (search_host.cpp free_view)
     uint32_t iterations;
     uint32_t rows;          // rows of a launch at most (512: pair tower; 1024: one pass of the chip)
     uint32_t ring;          // launches whose rows stay in the ring

@@ -89,7 +89,8 @@ def test_free_running_search_bit_exact_vs_oracle(eng, oracle, n, iters, pick, qu
 
 
 @pytest.mark.parametrize("opts", [dict(free_lds_nodes=64), dict(free_ring=4), dict(free_rows1024_from=129), dict(free_rows1024_from=1024),
-                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000), dict(free_lag_boost=0), dict(free_lag_boost=16, free_lag_step=1)])
+                                  dict(free_rollout_steps=48, free_cand_max=23), dict(free_rollout_steps=1, free_cand_max=1), dict(free_ring=4, free_lds_nodes=128), dict(free_iter_cap=1), dict(free_iter_cap=1000), dict(free_lag_boost=0), dict(free_lag_boost=16, free_lag_step=1),
+                                  dict(free_iter_cap=1, free_ring=4, free_cand_max=23), dict(free_iter_cap=1, free_ring=8, free_rollout_steps=1, free_lds_nodes=256)])
 def test_free_running_options_change_nothing(eng, oracle, opts):
     """the tree's nodes beyond the LDS capacity are read in place, a ring of 4 launches makes evaluations age out (they are demanded again:
     the same bits), 512- or 1024-row launches, many or few candidates, grants with and without a bonus for the games behind: the same search"""
