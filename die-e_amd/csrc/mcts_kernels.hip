@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(1024) void k_free_pack(Free F, uint32_t n, uint32_t
     const uint32_t rot = (q * 131u) % n;
     const uint32_t g = (uint32_t)tid < n ? ((uint32_t)tid + rot) % n : 0u;
     const uint32_t w = (uint32_t)tid < n ? F.wish_n[g] : ((F.iterations) << 8);
-    const uint32_t cnt = w & 0xffu, dem = w >> 31, spec = cnt - dem, prog = (w >> 8) & 0x7fffffu;
+    const uint32_t cnt = (w & 0xffu) < kFreeWish ? (w & 0xffu) : kFreeWish, dem = (w >> 31) < cnt ? (w >> 31) : cnt, spec = cnt - dem, prog = (w >> 8) & 0x7fffffu;   // (clamped: hist[] and the wish list hold kFreeWish entries)
     const bool undone = prog < F.iterations;
     if ((uint32_t)tid < n && undone) { atomicMax(&s_maxprog, prog); atomicAdd(&s_undone, 1u); if (dem) atomicAdd(&s_dem, 1u); }
     __syncthreads();
