@@ -2,7 +2,7 @@
 """Randomised self-consistency run of the free-running search: the engine against ITSELF (the launch-per-iteration search, which the
 parity suite holds to the oracle), so that hundreds of sizes / seeds / option mixes cost seconds instead of oracle minutes.
 
-    python tests/tools/free_fuzz.py [cases=300] [seed=1]
+    python tests/tools/free_fuzz.py [cases=300] [seed=1] [iters=8,16,...]
     python tests/tools/free_fuzz.py mode=selfplay [cases=20] [seed=1]      # whole batches: 20 ... 900 games (and 2-3 batches side by side)
                                                                           # played to completion through all three search paths
 
@@ -82,6 +82,8 @@ def main():
     if kv.get("mode") == "selfplay":
         return selfplay(int(kv.get("cases", 20)), int(kv.get("seed", 1)))
     cases, seed = int(kv.get("cases", 300)), int(kv.get("seed", 1))
+    # iterations per search (iters=1,2,3 on the command line for other mixes; 260: more rounds than the ring of 128 launches holds)
+    iter_choices = [int(x) for x in kv["iters"].split(",")] if "iters" in kv else [8, 16, 24, 40, 64, 100, 100, 260]
     rng = np.random.default_rng(seed)
     eng = diee_amd.Engine(0)
     eng.load_weights(diee_amd.random_weights(0))
@@ -92,7 +94,7 @@ def main():
     free_cases = 0
     for c in range(cases):
         n = int(rng.choice([rng.integers(2, 17), rng.integers(17, 41), rng.integers(41, 129), rng.integers(129, 257), rng.integers(257, 513), rng.integers(513, 801)]))
-        iters = int(rng.choice([8, 16, 24, 40, 64, 100, 100, 260]))          # (260: more rounds than the ring of 128 launches holds)
+        iters = int(rng.choice(iter_choices))
         w = int(rng.integers(0, len(walks)))
         share = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
         k = min(int(n * share), len(late[w]))
