@@ -187,3 +187,25 @@ def test_free_running_on_a_shared_gpu(oracle):
             assert r["stats"]["tail_iterations"] == iters and r["stats"]["tail_launches"] < iters
     finally:
         e.close()
+
+
+def test_free_running_reports_a_tree_arena_that_is_too_small(oracle):
+    """nodes_per_expansion = 1: the games' trees outgrow their arena in mid-search; the free-running search completes its rounds (no game
+    waits for a node that was never created), the call reports DIEE_ERR_CAPACITY, and the engine stays usable"""
+    import diee_amd
+    e = diee_amd.Engine(0)
+    e.load_weights(diee_amd.random_weights(0))
+    try:
+        states = roots_of(oracle, 300, "mixed")
+        e.set_option("nodes_per_expansion", 1)
+        with pytest.raises(diee_amd.DieeError) as ei:
+            e.alpha_mcts_parallel(states, diee_amd.MctsConfig.default(64), SEED, 0)
+        assert ei.value.status == diee_amd.ERR_CAPACITY
+        e.set_option("nodes_per_expansion", 128)
+        r = e.alpha_mcts_parallel(states, diee_amd.MctsConfig.default(16), SEED, 0)
+        e.set_options(free_eval=0, spec_eval=0)
+        plain = e.alpha_mcts_parallel(states, diee_amd.MctsConfig.default(16), SEED, 0)
+        assert r["stats"]["tail_iterations"] == 16 and plain["stats"]["tail_iterations"] == 0
+        assert r["probs"].tobytes() == plain["probs"].tobytes() and (r["n_children"] == plain["n_children"]).all()
+    finally:
+        e.close()
