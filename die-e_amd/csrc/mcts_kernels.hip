@@ -1114,8 +1114,9 @@ extern "C" int diee_dev_free_stamps(unsigned long long* out, int reset) {
 #define FR_COUNT(i, k) do {} while (0)
 #endif
 // a node in LDS: visits, value, prior, one header word (expanded / finished-game bits, children, first child), the ring row of its evaluation, and
-// the virtual descents' copy of visits / value -- 28 bytes (the action code of Tree::meta and the evaluation's value stay in HBM: read where needed)
-constexpr uint32_t kFreeLdsNodeBytes = 28;
+// its value (what a virtual descent that ends on the node adds), the virtual descents' copy of visits / value -- 32 bytes (the action code of
+// Tree::meta stays in HBM: read where needed)
+constexpr uint32_t kFreeLdsNodeBytes = 32;
 __host__ __device__ __forceinline__ constexpr uint32_t free_hdr(uint32_t meta, uint32_t first_child) {
     return (meta & 0xE0000000u) | (((meta >> 16) & 0x1ffu) << 20) | (first_child & 0xFFFFFu);
 }
@@ -1168,7 +1169,8 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     const uint32_t ln = F.lds_nodes;
     float* lvis = (float*)free_smem; float* lval = lvis + ln; float* lpri = lval + ln;
     float* vvis = lpri + ln; float* vval = vvis + ln;
-    uint32_t* lhdr = (uint32_t*)(vval + ln); uint32_t* lcrow = lhdr + ln;
+    float* lcval = vval + ln;
+    uint32_t* lhdr = (uint32_t*)(lcval + ln); uint32_t* lcrow = lhdr + ln;
     WaveScratch& ws = *reinterpret_cast<WaveScratch*>(lcrow + ln);
     float* raw = reinterpret_cast<float*>(&ws + 1);
     uint16_t* code = reinterpret_cast<uint16_t*>(raw + kMaxPlays);
@@ -1212,17 +1214,17 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
     // ---- the tree's statistics into LDS; the rows the previous launch evaluated for this game on top ----
     const uint32_t nl = used < ln ? used : ln;
     for (uint32_t i0 = 0; i0 < nl; i0 += 256) {                 // four rounds of loads in flight before the first store (a wave alone on its SIMD waits out every round trip)
-        float a[4], b[4], p[4]; uint32_t m[4], f[4], r[4];
+        float a[4], b[4], p[4], cv4[4]; uint32_t m[4], f[4], r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + 64u * u + (uint32_t)lane;
             const size_t gi = base + (i < nl ? i : 0u);
-            a[u] = T.visits[gi]; b[u] = T.value[gi]; p[u] = T.prior[gi]; m[u] = T.meta[gi]; f[u] = T.first_child[gi]; r[u] = crow_g[i < nl ? i : 0u];
+            a[u] = T.visits[gi]; b[u] = T.value[gi]; p[u] = T.prior[gi]; m[u] = T.meta[gi]; f[u] = T.first_child[gi]; r[u] = crow_g[i < nl ? i : 0u]; cv4[u] = cval_g[i < nl ? i : 0u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + 64u * u + (uint32_t)lane;
-            if (i < nl) { lvis[i] = a[u]; lval[i] = b[u]; lpri[i] = p[u]; lhdr[i] = free_hdr(m[u], f[u]); lcrow[i] = r[u]; }
+            if (i < nl) { lvis[i] = a[u]; lval[i] = b[u]; lpri[i] = p[u]; lhdr[i] = free_hdr(m[u], f[u]); lcrow[i] = r[u]; lcval[i] = cv4[u]; }
         }
     }
     __syncthreads();
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
             const float cv = tanhf(dot + S.wv[72]);
             const uint32_t id = ((pq << kFreeRowBits) | row) + 1u;
             cval_g[node] = cv; crow_g[node] = id;
-            if (node < ln) lcrow[node] = id;
+            if (node < ln) { lcrow[node] = id; lcval[node] = cv; }
         }
         cn[SC_NN_ROWS] += cnt;
         __syncthreads();
@@ -1501,13 +1503,14 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                     const uint32_t k = hdr_nch(mt);
                     if (k == 0) break;
                     const uint32_t fcn = hdr_fc(mt);
-                    const float sq = sqrtf(node < nu ? vvis[node] : T.visits[base + node]);
+                    // (a prediction, not the search: the hardware's approximate reciprocal and square root will do)
+                    const float sq = __builtin_amdgcn_sqrtf(node < nu ? vvis[node] : T.visits[base + node]);
                     Best b{0.0f, -1};
                     for (uint32_t j = lane; j < k; j += 64) {
                         const uint32_t ci = fcn + j;
                         const float vis = ci < nu ? vvis[ci] : T.visits[base + ci], val = ci < nu ? vval[ci] : T.value[base + ci];
-                        const float q = vis == 0.0f ? 0.0f : val / vis;
-                        const float sc_ = q + (c * (sq / (vis + 1.0f))) * X.pri(ci);
+                        const float q = vis == 0.0f ? 0.0f : val * __builtin_amdgcn_rcpf(vis);
+                        const float sc_ = q + (c * (sq * __builtin_amdgcn_rcpf(vis + 1.0f))) * X.pri(ci);
                         if (sc_ == sc_ && (b.j < 0 || !(b.s > sc_))) { b.s = sc_; b.j = (int)j; }
                     }
                     b = wave_best(b);
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(64) void k_free(Tree T, Slots S, Segs G, uint32_t n
                 float x = 0.0f;
                 bool fresh = false;
                 if (mt & kMetaTerminal) x = ((mt & kMetaWinnerPlus) ? 1 : -1) == root_player ? 1.0f : -1.0f;
-                else if (at_hand(cr)) x = cval_g[node];
+                else if (at_hand(cr)) x = node < ln ? lcval[node] : cval_g[node];
                 else if (!(mt & kDrained) && node != demanded) fresh = __ballot((uint32_t)lane < ncand && cand[lane] == node) == 0ull;
                 if (fresh) { if (lane == 0) { cand[ncand] = node; wl[nw + ncand] = node; } ++ncand; fruitless = 0; } else ++fruitless;
                 if ((uint32_t)lane <= depth && mine < nu) { vvis[mine] += 1.0f; vval[mine] += x; }
