@@ -209,3 +209,16 @@ def test_free_running_reports_a_tree_arena_that_is_too_small(oracle):
         assert r["probs"].tobytes() == plain["probs"].tobytes() and (r["n_children"] == plain["n_children"]).all()
     finally:
         e.close()
+
+
+def test_randomised_self_consistency_of_the_three_search_paths():
+    """tests/tools/free_fuzz.py in small: random sizes, seeds, iteration counts and option mixes (the free-running search's and k_tail's), the
+    default dispatch against the launch-per-iteration search -- which the cases above and tests/test_search_gpu.py hold to the oracle -- and
+    three whole self-play workloads; everything bit-identical.  (The long runs are in profiles/r06E ... r06M; this tool found free_run's round bound.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("free_fuzz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "free_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.search(120, 777, [1, 3, 8, 24, 64, 100]) == 0
+    assert fz.selfplay(3, 778) == 0

@@ -75,15 +75,19 @@ def selfplay(cases, seed):
 
 
 def main():
-    import diee_amd
-    from oracle import oracle                           # only random_walk_states: positions to search from
-    oracle.build()
     kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     if kv.get("mode") == "selfplay":
         return selfplay(int(kv.get("cases", 20)), int(kv.get("seed", 1)))
-    cases, seed = int(kv.get("cases", 300)), int(kv.get("seed", 1))
     # iterations per search (iters=1,2,3 on the command line for other mixes; 260: more rounds than the ring of 128 launches holds)
     iter_choices = [int(x) for x in kv["iters"].split(",")] if "iters" in kv else [8, 16, 24, 40, 64, 100, 100, 260]
+    return search(int(kv.get("cases", 300)), int(kv.get("seed", 1)), iter_choices)
+
+
+def search(cases, seed, iter_choices):
+    """single searches (diee_mcts_batch): the default dispatch and random option mixes against the launch-per-iteration search"""
+    import diee_amd
+    from oracle import oracle                           # only random_walk_states: positions to search from
+    oracle.build()
     rng = np.random.default_rng(seed)
     eng = diee_amd.Engine(0)
     eng.load_weights(diee_amd.random_weights(0))
